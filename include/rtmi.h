@@ -1,0 +1,256 @@
+/*
+ * rtmi.h — C ABI of librtmi.so, the MI355X (gfx950) implementation of the
+ * per-pixel path-tracing sample loop of MartinPuda/raytracing.
+ *
+ * The reference has no FFI of its own. The seam this library plugs into is the
+ * body of `-main` between camera construction and `display-image`
+ * (reference src/raytracing/core.clj:96-128): given the world vector built by
+ * the `scenes` constructors, the camera map and W, H, spp, depth, background,
+ * produce one packed-RGB `int` per pixel (what `setRGB` consumes at
+ * core.clj:123-126) and/or the per-pixel radiance sums.
+ *
+ * Conventions
+ *   - plain C types only; every pointer argument is caller-owned and only read
+ *     (or written, for outputs) during the call; the library copies what it keeps.
+ *   - return value: 0 = ok, negative = error (RT_ERR_*); rt_last_error() returns a
+ *     thread-local, library-owned message for the last failing call on this thread.
+ *   - no exceptions, no aborts, no callbacks cross this boundary.
+ *   - calls on one context must be serialised by the caller.
+ *   - there is no CPU fallback: without a HIP device rt_init fails with RT_ERR_HIP.
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMI_ABI_VERSION 1
+
+enum {
+  RT_OK = 0,
+  RT_ERR_ARG = -1,      /* malformed argument / scene description */
+  RT_ERR_HIP = -2,      /* HIP runtime error or no device */
+  RT_ERR_UNSUPPORTED = -3, /* valid reference construct this build cannot flatten */
+  RT_ERR_OOM = -4
+};
+
+/* ---- primitive kinds: one per reference Hittable leaf record ------------------ */
+enum {
+  RT_PRIM_SPHERE = 0,        /* base.clj:229-258   prim_d: cx cy cz r                      */
+  RT_PRIM_MOVING_SPHERE = 1, /* base.clj:263-302   prim_d: c0x c0y c0z c1x c1y c1z t0 t1 r */
+  RT_PRIM_XY_RECT = 2,       /* rectangles.clj:8-40    prim_d: x0 x1 y0 y1 k               */
+  RT_PRIM_XZ_RECT = 3,       /* rectangles.clj:45-77   prim_d: x0 x1 z0 z1 k               */
+  RT_PRIM_YZ_RECT = 4        /* rectangles.clj:82-114  prim_d: y0 y1 z0 z1 k               */
+};
+#define RT_PRIM_STRIDE 12    /* doubles per primitive in prim_d (unused tail = 0)         */
+
+/* ---- hittable tree nodes: one per reference Hittable aggregate / wrapper ------- */
+enum {
+  RT_NODE_PRIM = 0,      /* node_i: prim index, -, -, -                                   */
+  RT_NODE_LIST = 1,      /* HittableList / Box sides / the world vector
+                            (base.clj:90-101, box.clj:8-11). node_i: first, count into
+                            node_children (order = the reference's scan order)            */
+  RT_NODE_BVH = 2,       /* BvhNode (base.clj:116-124). node_i: left node, right node;
+                            node_d: box min xyz, box max xyz                              */
+  RT_NODE_TRANSLATE = 3, /* translate.clj:8-17. node_i: child node; node_d: offset xyz    */
+  RT_NODE_ROTATE_Y = 4,  /* rotate.clj:9-47.   node_i: child node; node_d: sin, cos       */
+  RT_NODE_MEDIUM = 5     /* constant_medium.clj:9-44. node_i: boundary node, phase
+                            material, medium index (0..n_media-1, DFS order);
+                            node_d: neg_inv_density                                       */
+};
+#define RT_NODE_ISTRIDE 4
+#define RT_NODE_DSTRIDE 6
+
+/* ---- materials (materials.clj) ------------------------------------------------- */
+enum {
+  RT_MAT_LAMBERTIAN = 0,    /* :14-24  mat_tex = albedo texture                            */
+  RT_MAT_METAL = 1,         /* :31-40  mat_d = albedo r g b, fuzz (as stored: the `metal`
+                                       constructor's clamp is the caller's job)           */
+  RT_MAT_DIELECTRIC = 2,    /* :45-62  mat_d = ir                                          */
+  RT_MAT_DIFFUSE_LIGHT = 3, /* :67-78  mat_tex = emit texture                              */
+  RT_MAT_ISOTROPIC = 4      /* :85-91  mat_tex = albedo texture                            */
+};
+#define RT_MAT_DSTRIDE 4
+
+/* ---- textures (texture.clj) ---------------------------------------------------- */
+enum {
+  RT_TEX_SOLID = 0,   /* :15-17  tex_d = r g b                                             */
+  RT_TEX_CHECKER = 1, /* :23-30  tex_i = odd texture, even texture                         */
+  RT_TEX_NOISE = 2,   /* :38-44  tex_i = perlin table index, scale (already truncated to
+                                 long as the record field does)                            */
+  RT_TEX_IMAGE = 3    /* :50-66  tex_i = image index, or -1 for the no-data texture
+                                 that returns [0 1 1]                                      */
+};
+#define RT_TEX_DSTRIDE 4
+#define RT_TEX_ISTRIDE 2
+
+/*
+ * Flat description of a world: what a host-side flattener produces by walking the
+ * reference's records ((:objects …), (:left/:right/:box …), (:ptr …), (:boundary …),
+ * (:sides …)). All geometry is FP64 exactly as the reference holds it; the library
+ * derives its own device formats.
+ */
+typedef struct rt_scene_desc {
+  int32_t abi_version;          /* RTMI_ABI_VERSION */
+
+  int32_t n_prims;
+  const int32_t* prim_type;     /* n_prims */
+  const double*  prim_d;        /* n_prims * RT_PRIM_STRIDE */
+  const int32_t* prim_mat;      /* n_prims */
+
+  int32_t n_nodes;
+  const int32_t* node_kind;     /* n_nodes */
+  const int32_t* node_i;        /* n_nodes * RT_NODE_ISTRIDE */
+  const double*  node_d;        /* n_nodes * RT_NODE_DSTRIDE */
+  int32_t n_children;
+  const int32_t* node_children; /* n_children: child node ids of LIST nodes */
+  int32_t root;                 /* node id of the world (normally a LIST) */
+  int32_t n_media;              /* number of RT_NODE_MEDIUM nodes */
+
+  int32_t n_mats;
+  const int32_t* mat_type;      /* n_mats */
+  const double*  mat_d;         /* n_mats * RT_MAT_DSTRIDE */
+  const int32_t* mat_tex;       /* n_mats (-1 when unused) */
+
+  int32_t n_tex;
+  const int32_t* tex_type;      /* n_tex */
+  const double*  tex_d;         /* n_tex * RT_TEX_DSTRIDE */
+  const int32_t* tex_i;         /* n_tex * RT_TEX_ISTRIDE */
+
+  int32_t n_perlin;             /* noise.clj:72-83: one table set per `perlin` call */
+  const double*  perlin_ranvec; /* n_perlin * 256 * 3 */
+  const int32_t* perlin_perm;   /* n_perlin * 3 * 256  (perm-x, perm-y, perm-z) */
+
+  int32_t n_images;             /* texture.clj:68-81: decoded on the host */
+  const int32_t* img_w;
+  const int32_t* img_h;
+  const uint8_t* const* img_rgb8; /* per image: h*w*3 bytes, top row first, R G B */
+} rt_scene_desc;
+
+/* The camera map, field for field (camera.clj:24-33). */
+typedef struct rt_camera {
+  double origin[3], lower_left_corner[3], horizontal[3], vertical[3];
+  double u[3], v[3], w[3];
+  double lens_radius, time0, time1;
+} rt_camera;
+
+/*
+ * One render request = the constants of `-main` (core.clj:52-59) plus sharding.
+ * A unit of work is one (pixel, sample); its random stream depends only on
+ * (seed, pixel index y*width+x, global sample index), so any split of the work
+ * over devices or calls reproduces the same per-sample radiance.
+ */
+typedef struct rt_params {
+  int32_t width, height;
+  int32_t spp;            /* samples rendered by THIS call per pixel                      */
+  int32_t sample_offset;  /* global index of this call's first sample (sample slicing)   */
+  int32_t max_depth;      /* core.clj:58 (50)                                             */
+  int32_t shard_index;    /* this call renders the 8x8-pixel tiles t with                 */
+  int32_t shard_count;    /*   t % shard_count == shard_index (row-major tile order)      */
+  int32_t flags;          /* RT_FLAG_*                                                    */
+  double  background[3];  /* core.clj:30,60-65                                            */
+  uint64_t seed;
+} rt_params;
+
+enum {
+  RT_FLAG_COUNTERS = 1    /* run the event-counting build of the path kernel and fill
+                             rt_stats.events (slower; never use its timing)               */
+};
+
+/* Event counters, indexed by RT_EV_*; the unit costs live next to the enum. */
+enum {
+  RT_EV_AABB_TEST = 0, RT_EV_SPHERE_TEST, RT_EV_SPHERE_ROOT, RT_EV_SPHERE_RECORD,
+  RT_EV_MSPHERE_CENTER, RT_EV_RECT_TEST, RT_EV_RECT_RECORD,
+  RT_EV_ROTATE_RAY, RT_EV_ROTATE_REC, RT_EV_TRANSLATE_RAY, RT_EV_TRANSLATE_REC,
+  RT_EV_MEDIUM_SAMPLE, RT_EV_CAMERA_RAY, RT_EV_SPHERE_TRIAL, RT_EV_DISK_TRIAL,
+  RT_EV_LAMBERT, RT_EV_METAL, RT_EV_DIELECTRIC, RT_EV_ISOTROPIC, RT_EV_LIGHT,
+  RT_EV_CHECKER, RT_EV_PERLIN_NOISE, RT_EV_NOISE_TEX, RT_EV_IMAGE_TEX,
+  RT_EV_THROUGHPUT, RT_EV_ACCUMULATE,
+  RT_EV_COUNT
+};
+
+typedef struct rt_stats {
+  uint64_t samples;              /* camera paths started                                  */
+  uint64_t rays;                 /* ray-color invocations that reached `hit` (core.clj:23) */
+  uint64_t events[RT_EV_COUNT];  /* only with RT_FLAG_COUNTERS, else 0                    */
+  double   kernel_ms;            /* HIP-event time of the path kernel alone, on its stream */
+} rt_stats;
+
+/* One closest-hit record = the reference's HitRecord (base.clj:169) as `ray-color`
+ * would receive it from (hit (->HittableList world) r t-min t-max {}). */
+typedef struct rt_hit {
+  float t, p[3], normal[3], u, v;
+  int32_t front_face, mat_id, hit; /* hit = 0: miss (all other fields 0) */
+} rt_hit;
+
+typedef struct rt_ctx rt_ctx;
+typedef struct rt_scene rt_scene;
+
+/* Binds the context to one HIP device (one process per GPU). Replaces nothing in the
+ * reference (it has no device notion); it is the price of entry for every other call. */
+int rt_init(int32_t device_id, rt_ctx** out);
+void rt_shutdown(rt_ctx* ctx);
+const char* rt_last_error(void);
+int rt_abi_version(void);
+
+/* Uploads a world and builds its device form (flattened instance chains, GPU-built BVHs).
+ * Stands in for holding the `world` vector that core.clj:66-88 selects. */
+int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* The sample loop of core.clj:96-127 over this call's shard of tiles and slice of samples.
+ *   rgb_sum: width*height*3 floats, row 0 = y 0 = BOTTOM image row (the reference flips rows
+ *            only when writing to the BufferedImage, core.clj:123-126); sums over this call's
+ *            samples; pixels of other shards are written as 0. May be NULL.
+ *   argb:    width*height packed 0xFFRRGGBB after x(1/spp) -> sqrt -> clamp[0,0.999] ->
+ *            (int)(c*255+0.5), NaN -> 0 (core.clj:106-108,118,121-122; java.awt.Color(float,
+ *            float,float)); only meaningful when the call covers all samples of its pixels.
+ *            May be NULL.
+ *   stats:   may be NULL.
+ * rt_render takes HOST buffers (copies back over PCIe); rt_render_device takes DEVICE
+ * buffers on the context's GPU and enqueues on `hip_stream` (a hipStream_t, NULL = the
+ * null stream) without synchronising unless stats is non-NULL. */
+int rt_render(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, const rt_params* params,
+              float* rgb_sum, uint32_t* argb, rt_stats* stats);
+int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam,
+                     const rt_params* params, float* d_rgb_sum, uint32_t* d_argb,
+                     rt_stats* stats, void* hip_stream);
+
+/* The post-process of core.clj:106-108,118,121-122 alone, device buffers: used on the root
+ * rank after per-GPU sums have been combined. `spp_total` is the divisor. */
+int rt_tonemap_device(rt_ctx* ctx, const float* d_rgb_sum, int32_t n_pixels, int32_t spp_total,
+                      uint32_t* d_argb, void* hip_stream);
+
+/* Parity hook: closest hit for a batch of rays exactly as ray-color's `hit` call would
+ * return it (core.clj:23). orig3/dir3: n*3 floats, time: n floats (NULL = 0).
+ * medium_xi: n * n_media scripted uniforms for the free-flight draw of each medium
+ * (constant_medium.clj:32), or NULL to skip MEDIUM nodes. Host buffers. */
+int rt_hit_batch(rt_ctx* ctx, const rt_scene* scene, int32_t n, const float* orig3,
+                 const float* dir3, const float* time, float t_min, float t_max,
+                 const float* medium_xi, rt_hit* out);
+
+/* Parity hook for the scatter/texture functions: per-sample radiance of single samples,
+ * host buffers. For i in [0,n): pixel index px[i], global sample index smp[i] ->
+ * out_rgb[3*i..] = ray-color of that one camera path (core.clj:96-105). */
+int rt_sample_batch(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam,
+                    const rt_params* params, int32_t n, const int32_t* px, const int32_t* smp,
+                    float* out_rgb);
+
+/* Introspection for tests and reports. */
+typedef struct rt_scene_info {
+  int32_t n_prims_flat;   /* leaves reachable from the root, deduplicated          */
+  int32_t n_groups;       /* (instance chain, primitive set) groups                */
+  int32_t n_chains;
+  int32_t n_media;
+  int32_t n_bvh_nodes;    /* over all GPU-built BVHs                               */
+  int32_t lds_bytes;      /* per-workgroup LDS the path kernel uses for this scene */
+} rt_scene_info;
+int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMI_H */

@@ -1,0 +1,712 @@
+// rt_api.hip — the C ABI of include/rtmi.h: validation, the host-side rewrite of the flat scene
+// description into the device layout of rt_scene.h, uploads, and the render / parity entry
+// points. No C++ type, exception or abort crosses this boundary.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <new>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/rtmi.h"
+#include "rt_launch.h"
+#include "rt_scene.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP,   \
+                                      "%s failed: %s", #expr, hipGetErrorString(e_));        \
+  } while (0)
+
+}  // namespace
+
+struct rt_ctx {
+  int device = 0;
+  int n_cu = 0;
+  // reusable device workspace
+  uint32_t* d_queue = nullptr;              // 1 word: head of the work-item queue
+  unsigned long long* d_stats = nullptr;    // 2 + RT_EV_COUNT words
+  float* d_partial = nullptr;               // n_chunks * W*H*3 partial sums
+  size_t partial_bytes = 0;
+  void* d_io = nullptr;                     // staging for the host-buffer entry points
+  size_t io_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct rt_scene {
+  rt_ctx* ctx = nullptr;
+  DScene S{};
+  std::vector<void*> allocs;
+  rt_scene_info info{};
+  int n_media = 0;
+  bool has_time_bounds = false;
+  float time_lo = 0.f, time_hi = 1.f;
+  int blocks_per_cu[2] = {0, 0};  // occupancy of k_render<false>, k_render<true>
+};
+
+namespace {
+
+int ensure_io(rt_ctx* ctx, size_t bytes) {
+  if (ctx->io_bytes >= bytes) return RT_OK;
+  if (ctx->d_io) hipFree(ctx->d_io);
+  ctx->d_io = nullptr;
+  ctx->io_bytes = 0;
+  HIPCHK(hipMalloc(&ctx->d_io, bytes));
+  ctx->io_bytes = bytes;
+  return RT_OK;
+}
+
+// ----------------------------------------------------------------------------- validation
+bool finite_all(const double* p, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (!std::isfinite(p[i])) return false;
+  return true;
+}
+
+int validate_desc(const rt_scene_desc* d) {
+  if (!d) return fail(RT_ERR_ARG, "scene description is NULL");
+  if (d->abi_version != RTMI_ABI_VERSION)
+    return fail(RT_ERR_ARG, "abi_version %d, library speaks %d", d->abi_version, RTMI_ABI_VERSION);
+  if (d->n_prims < 0 || d->n_nodes <= 0 || d->n_children < 0 || d->n_mats < 0 || d->n_tex < 0 ||
+      d->n_perlin < 0 || d->n_images < 0 || d->n_media < 0)
+    return fail(RT_ERR_ARG, "negative or empty count in scene description");
+  if (d->root < 0 || d->root >= d->n_nodes) return fail(RT_ERR_ARG, "root node %d out of range", d->root);
+  if ((d->n_prims && (!d->prim_type || !d->prim_d || !d->prim_mat)) || !d->node_kind || !d->node_i || !d->node_d ||
+      (d->n_children && !d->node_children) || (d->n_mats && (!d->mat_type || !d->mat_d || !d->mat_tex)) ||
+      (d->n_tex && (!d->tex_type || !d->tex_d || !d->tex_i)) || (d->n_perlin && (!d->perlin_ranvec || !d->perlin_perm)) ||
+      (d->n_images && (!d->img_w || !d->img_h || !d->img_rgb8)))
+    return fail(RT_ERR_ARG, "NULL array with a non-zero count in scene description");
+  for (int i = 0; i < d->n_prims; ++i) {
+    int t = d->prim_type[i];
+    if (t < RT_PRIM_SPHERE || t > RT_PRIM_YZ_RECT) return fail(RT_ERR_ARG, "prim %d: unknown type %d", i, t);
+    if (d->prim_mat[i] < 0 || d->prim_mat[i] >= d->n_mats) return fail(RT_ERR_ARG, "prim %d: material out of range", i);
+    if (!finite_all(d->prim_d + (size_t)i * RT_PRIM_STRIDE, RT_PRIM_STRIDE))
+      return fail(RT_ERR_ARG, "prim %d: non-finite parameter", i);
+  }
+  for (int i = 0; i < d->n_mats; ++i) {
+    int t = d->mat_type[i];
+    if (t < RT_MAT_LAMBERTIAN || t > RT_MAT_ISOTROPIC) return fail(RT_ERR_ARG, "material %d: unknown type %d", i, t);
+    bool textured = t == RT_MAT_LAMBERTIAN || t == RT_MAT_DIFFUSE_LIGHT || t == RT_MAT_ISOTROPIC;
+    if (textured && (d->mat_tex[i] < 0 || d->mat_tex[i] >= d->n_tex))
+      return fail(RT_ERR_ARG, "material %d: texture out of range", i);
+  }
+  for (int i = 0; i < d->n_tex; ++i) {
+    int t = d->tex_type[i];
+    const int32_t* ti = d->tex_i + (size_t)i * RT_TEX_ISTRIDE;
+    if (t < RT_TEX_SOLID || t > RT_TEX_IMAGE) return fail(RT_ERR_ARG, "texture %d: unknown type %d", i, t);
+    if (t == RT_TEX_CHECKER && (ti[0] < 0 || ti[0] >= d->n_tex || ti[1] < 0 || ti[1] >= d->n_tex))
+      return fail(RT_ERR_ARG, "texture %d: checker branch out of range", i);
+    if (t == RT_TEX_NOISE && (ti[0] < 0 || ti[0] >= d->n_perlin)) return fail(RT_ERR_ARG, "texture %d: perlin id out of range", i);
+    if (t == RT_TEX_IMAGE && ti[0] >= d->n_images) return fail(RT_ERR_ARG, "texture %d: image id out of range", i);
+  }
+  // checker textures must bottom out within the depth the kernels walk
+  for (int i = 0; i < d->n_tex; ++i) {
+    std::vector<std::pair<int, int>> st{{i, 0}};
+    while (!st.empty()) {
+      auto [t, depth] = st.back();
+      st.pop_back();
+      if (d->tex_type[t] != RT_TEX_CHECKER) continue;
+      if (depth >= 15) return fail(RT_ERR_UNSUPPORTED, "texture %d: checker nesting deeper than 15 (or cyclic)", i);
+      st.push_back({d->tex_i[(size_t)t * RT_TEX_ISTRIDE], depth + 1});
+      st.push_back({d->tex_i[(size_t)t * RT_TEX_ISTRIDE + 1], depth + 1});
+    }
+  }
+  for (int i = 0; i < d->n_perlin * 3 * 256; ++i)
+    if (d->perlin_perm[i] < 0 || d->perlin_perm[i] > 255) return fail(RT_ERR_ARG, "perlin permutation entry out of 0..255");
+  for (int i = 0; i < d->n_images; ++i)
+    if (d->img_w[i] <= 0 || d->img_h[i] <= 0 || !d->img_rgb8[i]) return fail(RT_ERR_ARG, "image %d: bad size or NULL data", i);
+  std::vector<char> medium_seen((size_t)d->n_media, 0);
+  for (int i = 0; i < d->n_nodes; ++i) {
+    const int32_t* ni = d->node_i + (size_t)i * RT_NODE_ISTRIDE;
+    auto node_ok = [&](int n) { return n >= 0 && n < d->n_nodes; };
+    switch (d->node_kind[i]) {
+      case RT_NODE_PRIM:
+        if (ni[0] < 0 || ni[0] >= d->n_prims) return fail(RT_ERR_ARG, "node %d: prim out of range", i);
+        break;
+      case RT_NODE_LIST:
+        if (ni[0] < 0 || ni[1] < 0 || (long long)ni[0] + ni[1] > d->n_children)
+          return fail(RT_ERR_ARG, "node %d: child range out of bounds", i);
+        for (int c = 0; c < ni[1]; ++c)
+          if (!node_ok(d->node_children[ni[0] + c])) return fail(RT_ERR_ARG, "node %d: child out of range", i);
+        break;
+      case RT_NODE_BVH:
+        if (!node_ok(ni[0]) || !node_ok(ni[1])) return fail(RT_ERR_ARG, "node %d: bvh child out of range", i);
+        break;
+      case RT_NODE_TRANSLATE:
+      case RT_NODE_ROTATE_Y:
+        if (!node_ok(ni[0])) return fail(RT_ERR_ARG, "node %d: child out of range", i);
+        if (!finite_all(d->node_d + (size_t)i * RT_NODE_DSTRIDE, 3)) return fail(RT_ERR_ARG, "node %d: non-finite transform", i);
+        break;
+      case RT_NODE_MEDIUM:
+        if (!node_ok(ni[0])) return fail(RT_ERR_ARG, "node %d: boundary out of range", i);
+        if (ni[1] < 0 || ni[1] >= d->n_mats) return fail(RT_ERR_ARG, "node %d: phase material out of range", i);
+        if (ni[2] < 0 || ni[2] >= d->n_media || medium_seen[ni[2]]++) return fail(RT_ERR_ARG, "node %d: medium index invalid or repeated", i);
+        break;
+      default:
+        return fail(RT_ERR_ARG, "node %d: unknown kind %d", i, d->node_kind[i]);
+    }
+  }
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------------------ flattening
+struct Sink {  // leaves reached under each chain, in scan order, duplicates dropped
+  std::vector<int> chain_order;
+  std::map<int, std::vector<int>> prims;
+  std::set<std::pair<int, int>> seen;
+  void add(int chain, int prim) {
+    if (!seen.insert({chain, prim}).second) return;
+    if (!prims.count(chain)) chain_order.push_back(chain);
+    prims[chain].push_back(prim);
+  }
+};
+
+struct HostMedium {
+  int outer_chain = 0, phase_mat = 0;
+  float neg_inv_density = 0.f;
+  Sink boundary;
+  bool present = false;
+};
+
+struct Flattener {
+  const rt_scene_desc* d;
+  std::vector<std::vector<DChainOp>> chains{{}};  // chain 0 = identity
+  Sink surface;
+  std::vector<HostMedium> media;
+  std::vector<char> on_stack;
+  int err = RT_OK;
+
+  int intern(const std::vector<DChainOp>& ops) {
+    for (size_t i = 0; i < chains.size(); ++i) {
+      if (chains[i].size() != ops.size()) continue;
+      if (ops.empty() || std::memcmp(chains[i].data(), ops.data(), ops.size() * sizeof(DChainOp)) == 0) return (int)i;
+    }
+    chains.push_back(ops);
+    return (int)chains.size() - 1;
+  }
+
+  void walk(int node, int chain, Sink& sink, bool in_boundary) {
+    if (err) return;
+    if (on_stack[node]) { err = fail(RT_ERR_ARG, "node %d: the hittable tree has a cycle", node); return; }
+    on_stack[node] = 1;
+    const int32_t* ni = d->node_i + (size_t)node * RT_NODE_ISTRIDE;
+    const double* nd = d->node_d + (size_t)node * RT_NODE_DSTRIDE;
+    switch (d->node_kind[node]) {
+      case RT_NODE_PRIM:
+        sink.add(chain, ni[0]);
+        break;
+      case RT_NODE_LIST:
+        for (int c = 0; c < ni[1] && !err; ++c) walk(d->node_children[ni[0] + c], chain, sink, in_boundary);
+        break;
+      case RT_NODE_BVH:
+        walk(ni[0], chain, sink, in_boundary);
+        walk(ni[1], chain, sink, in_boundary);
+        break;
+      case RT_NODE_TRANSLATE:
+      case RT_NODE_ROTATE_Y: {
+        std::vector<DChainOp> ops = chains[chain];
+        if (ops.size() >= RT_MAX_CHAIN_OPS) {
+          err = fail(RT_ERR_UNSUPPORTED, "node %d: more than %d nested translate/rotate-y wrappers", node, RT_MAX_CHAIN_OPS);
+          break;
+        }
+        DChainOp op;
+        std::memset(&op, 0, sizeof op);
+        if (d->node_kind[node] == RT_NODE_TRANSLATE) {
+          op.kind = DOP_TRANSLATE; op.a = (float)nd[0]; op.b = (float)nd[1]; op.c = (float)nd[2];
+        } else {
+          op.kind = DOP_ROTATE_Y; op.a = (float)nd[0]; op.b = (float)nd[1];
+        }
+        ops.push_back(op);
+        walk(ni[0], intern(ops), sink, in_boundary);
+        break;
+      }
+      case RT_NODE_MEDIUM: {
+        if (in_boundary) {
+          err = fail(RT_ERR_UNSUPPORTED, "node %d: a constant medium inside another medium's boundary", node);
+          break;
+        }
+        HostMedium& M = media[ni[2]];
+        M.present = true;
+        M.outer_chain = chain;
+        M.phase_mat = ni[1];
+        M.neg_inv_density = (float)nd[0];
+        walk(ni[0], chain, M.boundary, true);
+        break;
+      }
+    }
+    on_stack[node] = 0;
+  }
+};
+
+template <class T>
+int upload(rt_scene* sc, const std::vector<T>& v, const T** out) {
+  *out = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, bytes));
+  sc->allocs.push_back(p);
+  if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = static_cast<const T*>(p);
+  return RT_OK;
+}
+
+bool tex_needs_uv(const rt_scene_desc* d, int tex, int depth = 0) {
+  if (tex < 0 || depth > 16) return false;
+  int t = d->tex_type[tex];
+  if (t == RT_TEX_IMAGE) return true;
+  if (t == RT_TEX_CHECKER)
+    return tex_needs_uv(d, d->tex_i[(size_t)tex * RT_TEX_ISTRIDE], depth + 1) ||
+           tex_needs_uv(d, d->tex_i[(size_t)tex * RT_TEX_ISTRIDE + 1], depth + 1);
+  return false;
+}
+
+void fill_camera(const rt_camera* c, DCamera& o) {
+  for (int a = 0; a < 3; ++a) {
+    o.origin[a] = c->origin[a]; o.llc[a] = c->lower_left_corner[a];
+    o.horizontal[a] = c->horizontal[a]; o.vertical[a] = c->vertical[a];
+    o.u[a] = c->u[a]; o.v[a] = c->v[a];
+  }
+  o.lens_radius = c->lens_radius; o.time0 = c->time0; o.time1 = c->time1;
+}
+
+int fill_render(const rt_scene* sc, const rt_camera* cam, const rt_params* p, DRender& R) {
+  if (!cam || !p) return fail(RT_ERR_ARG, "camera or params is NULL");
+  if (p->width <= 0 || p->height <= 0 || (long long)p->width * p->height > (1ll << 28))
+    return fail(RT_ERR_ARG, "image size %dx%d out of range", p->width, p->height);
+  if (p->spp <= 0 || p->sample_offset < 0 || p->max_depth < 0 || p->max_depth > (1 << 26))
+    return fail(RT_ERR_ARG, "spp %d / sample_offset %d / max_depth %d out of range", p->spp, p->sample_offset, p->max_depth);
+  int sc_count = p->shard_count <= 0 ? 1 : p->shard_count;
+  if (p->shard_index < 0 || p->shard_index >= sc_count) return fail(RT_ERR_ARG, "shard %d of %d", p->shard_index, sc_count);
+  if (sc->has_time_bounds) {
+    double lo = std::min(cam->time0, cam->time1), hi = std::max(cam->time0, cam->time1);
+    if (lo < sc->time_lo || hi > sc->time_hi)
+      return fail(RT_ERR_ARG, "camera shutter [%g, %g] leaves the interval [%g, %g] moving spheres are bounded for",
+                  lo, hi, sc->time_lo, sc->time_hi);
+  }
+  R.width = p->width; R.height = p->height;
+  R.spp = p->spp; R.sample_offset = p->sample_offset; R.max_depth = p->max_depth;
+  R.shard_index = p->shard_index; R.shard_count = sc_count;
+  R.tiles_x = (p->width + RT_TILE - 1) / RT_TILE;
+  R.tiles_y = (p->height + RT_TILE - 1) / RT_TILE;
+  int n_tiles = R.tiles_x * R.tiles_y;
+  R.n_owned_tiles = n_tiles > R.shard_index ? (n_tiles - R.shard_index + sc_count - 1) / sc_count : 0;
+  // Samples per work item depend on spp alone, so the FP32 summation order of a pixel does not
+  // depend on how the image is sharded.
+  int n_chunks = std::min(p->spp, 32);
+  R.chunk = (p->spp + n_chunks - 1) / n_chunks;
+  R.n_chunks = (p->spp + R.chunk - 1) / R.chunk;
+  long long n_items = (long long)R.n_owned_tiles * 64 * R.n_chunks;
+  if (n_items > 0x7fffffffll - 4096) return fail(RT_ERR_ARG, "too many work items (%lld)", n_items);
+  R.n_items = (int)n_items;
+  R.batch = 64;
+  for (int a = 0; a < 3; ++a) R.bg[a] = (float)p->background[a];
+  R.seed_lo = (uint32_t)p->seed; R.seed_hi = (uint32_t)(p->seed >> 32);
+  return RT_OK;
+}
+
+}  // namespace
+
+// ========================================================================== the C ABI
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+int rt_abi_version(void) { return RTMI_ABI_VERSION; }
+
+int rt_init(int32_t device_id, rt_ctx** out) {
+  if (!out) return fail(RT_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(RT_ERR_HIP, "no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= n) return fail(RT_ERR_ARG, "device %d out of range (have %d)", device_id, n);
+  HIPCHK(hipSetDevice(device_id));
+  rt_ctx* ctx = new (std::nothrow) rt_ctx();
+  if (!ctx) return fail(RT_ERR_OOM, "out of host memory");
+  ctx->device = device_id;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device_id));
+  ctx->n_cu = prop.multiProcessorCount;
+  HIPCHK(hipMalloc(&ctx->d_queue, 256));
+  HIPCHK(hipMalloc(&ctx->d_stats, sizeof(unsigned long long) * (2 + RT_EV_COUNT)));
+  HIPCHK(hipEventCreate(&ctx->ev0));
+  HIPCHK(hipEventCreate(&ctx->ev1));
+  *out = ctx;
+  return RT_OK;
+}
+
+void rt_shutdown(rt_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipFree(ctx->d_queue);
+  hipFree(ctx->d_stats);
+  hipFree(ctx->d_partial);
+  hipFree(ctx->d_io);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  delete ctx;
+}
+
+void rt_scene_destroy(rt_scene* sc) {
+  if (!sc) return;
+  if (sc->ctx) hipSetDevice(sc->ctx->device);
+  for (void* p : sc->allocs) hipFree(p);
+  delete sc;
+}
+
+int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
+  if (!ctx || !out) return fail(RT_ERR_ARG, "ctx or out is NULL");
+  *out = nullptr;
+  int rc = validate_desc(d);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+
+  Flattener F;
+  F.d = d;
+  F.media.resize((size_t)d->n_media);
+  F.on_stack.assign((size_t)d->n_nodes, 0);
+  F.walk(d->root, 0, F.surface, false);
+  if (F.err) return F.err;
+
+  // device primitive records, one contiguous run per group
+  std::vector<DPrim> prims;
+  std::vector<DGroup> groups;
+  bool any_moving = false;
+  double tlo = 0.0, thi = 1.0;
+  auto emit_groups = [&](const Sink& sink) {
+    for (int chain : sink.chain_order) {
+      const std::vector<int>& list = sink.prims.at(chain);
+      DGroup G{chain, (int)prims.size(), (int)list.size(), -1};
+      for (int pi : list) {
+        DPrim P;
+        std::memset(&P, 0, sizeof P);
+        P.type = d->prim_type[pi];
+        P.mat = d->prim_mat[pi];
+        const double* pd = d->prim_d + (size_t)pi * RT_PRIM_STRIDE;
+        if (P.type == RT_PRIM_SPHERE) {
+          for (int k = 0; k < 4; ++k) P.d[k] = pd[k];
+        } else if (P.type == RT_PRIM_MOVING_SPHERE) {
+          for (int k = 0; k < 9; ++k) P.d[k] = pd[k];
+          any_moving = true;
+          tlo = std::min(tlo, std::min(pd[6], pd[7]));
+          thi = std::max(thi, std::max(pd[6], pd[7]));
+        } else {
+          for (int k = 0; k < 5; ++k) P.f[k] = (float)pd[k];
+        }
+        prims.push_back(P);
+      }
+      groups.push_back(G);
+    }
+  };
+  emit_groups(F.surface);
+  int n_surface_groups = (int)groups.size();
+  std::vector<DMedium> media((size_t)d->n_media);
+  for (int m = 0; m < d->n_media; ++m) {
+    HostMedium& M = F.media[m];
+    DMedium dm;
+    std::memset(&dm, 0, sizeof dm);
+    dm.first_group = (int)groups.size();
+    if (M.present) {
+      emit_groups(M.boundary);
+      dm.outer_chain = M.outer_chain;
+      dm.phase_mat = M.phase_mat;
+      dm.neg_inv_density = M.neg_inv_density;
+    }
+    dm.n_groups = (int)groups.size() - dm.first_group;  // 0 for a medium the root never reaches
+    media[m] = dm;
+  }
+
+  std::vector<DChain> chains;
+  std::vector<DChainOp> ops;
+  for (auto& c : F.chains) {
+    chains.push_back(DChain{(int)ops.size(), (int)c.size()});
+    ops.insert(ops.end(), c.begin(), c.end());
+  }
+
+  std::vector<DMat> mats((size_t)d->n_mats);
+  for (int i = 0; i < d->n_mats; ++i) {
+    const double* md = d->mat_d + (size_t)i * RT_MAT_DSTRIDE;
+    DMat M;
+    std::memset(&M, 0, sizeof M);
+    M.type = d->mat_type[i];
+    M.tex = d->mat_tex[i];
+    M.needs_uv = tex_needs_uv(d, d->mat_tex[i]) ? 1 : 0;
+    M.r = (float)md[0]; M.g = (float)md[1]; M.b = (float)md[2]; M.x = (float)md[3];
+    mats[i] = M;
+  }
+  std::vector<DTex> texs((size_t)d->n_tex);
+  for (int i = 0; i < d->n_tex; ++i) {
+    DTex T;
+    std::memset(&T, 0, sizeof T);
+    T.type = d->tex_type[i];
+    T.i0 = d->tex_i[(size_t)i * RT_TEX_ISTRIDE];
+    T.i1 = d->tex_i[(size_t)i * RT_TEX_ISTRIDE + 1];
+    T.r = (float)d->tex_d[(size_t)i * RT_TEX_DSTRIDE];
+    T.g = (float)d->tex_d[(size_t)i * RT_TEX_DSTRIDE + 1];
+    T.b = (float)d->tex_d[(size_t)i * RT_TEX_DSTRIDE + 2];
+    texs[i] = T;
+  }
+  if (d->n_perlin > RT_MAX_PERLIN_LDS)
+    return fail(RT_ERR_UNSUPPORTED, "%d Perlin table sets; at most %d fit the LDS budget", d->n_perlin, RT_MAX_PERLIN_LDS);
+  std::vector<float> pvec((size_t)d->n_perlin * 256 * 4, 0.f);
+  std::vector<uint8_t> pperm((size_t)d->n_perlin * 768, 0);
+  for (int i = 0; i < d->n_perlin * 256; ++i)
+    for (int k = 0; k < 3; ++k) pvec[(size_t)i * 4 + k] = (float)d->perlin_ranvec[(size_t)i * 3 + k];
+  for (int i = 0; i < d->n_perlin * 768; ++i) pperm[i] = (uint8_t)d->perlin_perm[i];
+  std::vector<DImage> images((size_t)d->n_images);
+  std::vector<uint32_t> texels;
+  for (int i = 0; i < d->n_images; ++i) {
+    DImage I{d->img_w[i], d->img_h[i], (int)texels.size(), 0};
+    size_t n = (size_t)I.w * I.h;
+    if (texels.size() + n > 0x7fffffffull) return fail(RT_ERR_UNSUPPORTED, "image textures exceed 2^31 texels");
+    const uint8_t* src = d->img_rgb8[i];
+    for (size_t t = 0; t < n; ++t)
+      texels.push_back((uint32_t)src[3 * t] | ((uint32_t)src[3 * t + 1] << 8) | ((uint32_t)src[3 * t + 2] << 16));
+    images[i] = I;
+  }
+
+  rt_scene* sc = new (std::nothrow) rt_scene();
+  if (!sc) return fail(RT_ERR_OOM, "out of host memory");
+  sc->ctx = ctx;
+  sc->n_media = d->n_media;
+  sc->has_time_bounds = any_moving;
+  sc->time_lo = (float)tlo;
+  sc->time_hi = (float)thi;
+  struct Guard {
+    rt_scene* s;
+    ~Guard() { if (s) rt_scene_destroy(s); }
+  } guard{sc};
+
+  DScene& S = sc->S;
+  const DPrim* d_prims = nullptr;
+  if ((rc = upload(sc, prims, &d_prims))) return rc;
+  S.prims = d_prims;
+
+  // BVHs for the large groups, built on the device
+  int n_bvh_nodes = 0;
+  for (auto& G : groups)
+    if (G.n_prims > RT_BRUTE_MAX) n_bvh_nodes += G.n_prims - 1;
+  DBvhNode* d_nodes = nullptr;
+  {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, sizeof(DBvhNode) * (size_t)std::max(n_bvh_nodes, 1)));
+    sc->allocs.push_back(p);
+    HIPCHK(hipMemset(p, 0, sizeof(DBvhNode) * (size_t)std::max(n_bvh_nodes, 1)));
+    d_nodes = static_cast<DBvhNode*>(p);
+  }
+  int node_base = 0, max_height = 0;
+  for (auto& G : groups) {
+    if (G.n_prims <= RT_BRUTE_MAX) continue;
+    int height = 0;
+    hipError_t e = build_bvh(d_prims, G.first_prim, G.n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e));
+    G.bvh_root = node_base;
+    node_base += G.n_prims - 1;
+    max_height = std::max(max_height, height);
+  }
+  S.nodes = d_nodes;
+  S.bvh_stack = n_bvh_nodes ? max_height + 1 : 0;
+
+  if ((rc = upload(sc, groups, &S.groups))) return rc;
+  if ((rc = upload(sc, chains, &S.chains))) return rc;
+  if ((rc = upload(sc, ops, &S.ops))) return rc;
+  if ((rc = upload(sc, media, &S.media))) return rc;
+  if ((rc = upload(sc, mats, &S.mats))) return rc;
+  if ((rc = upload(sc, texs, &S.texs))) return rc;
+  if ((rc = upload(sc, pvec, &S.perlin_vec))) return rc;
+  if ((rc = upload(sc, pperm, &S.perlin_perm))) return rc;
+  if ((rc = upload(sc, images, &S.images))) return rc;
+  if ((rc = upload(sc, texels, &S.texels))) return rc;
+  S.n_surface_groups = n_surface_groups;
+  S.n_groups = (int)groups.size();
+  S.n_media = d->n_media;
+  S.n_perlin = d->n_perlin;
+
+  size_t lds = shade_lds_bytes(S, RT_BLOCK);
+  if (lds > 64 * 1024)
+    return fail(RT_ERR_UNSUPPORTED, "scene needs %zu bytes of LDS per workgroup (BVH height %d); limit is 65536", lds, max_height);
+  HIPCHK(render_occupancy(S, false, &sc->blocks_per_cu[0]));
+  HIPCHK(render_occupancy(S, true, &sc->blocks_per_cu[1]));
+  if (sc->blocks_per_cu[0] < 1 || sc->blocks_per_cu[1] < 1) return fail(RT_ERR_HIP, "path kernel does not fit a compute unit");
+
+  sc->info.n_prims_flat = (int)prims.size();
+  sc->info.n_groups = (int)groups.size();
+  sc->info.n_chains = (int)chains.size();
+  sc->info.n_media = d->n_media;
+  sc->info.n_bvh_nodes = n_bvh_nodes;
+  sc->info.lds_bytes = (int)lds;
+  guard.s = nullptr;
+  *out = sc;
+  return RT_OK;
+}
+
+int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
+  if (!sc || !out) return fail(RT_ERR_ARG, "scene or out is NULL");
+  *out = sc->info;
+  return RT_OK;
+}
+
+int rt_render_device(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, float* d_rgb_sum,
+                     uint32_t* d_argb, rt_stats* stats, void* hip_stream) {
+  if (!ctx || !sc || sc->ctx != ctx) return fail(RT_ERR_ARG, "ctx/scene is NULL or the scene belongs to another context");
+  DRender R;
+  int rc = fill_render(sc, cam, p, R);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  DCamera C;
+  fill_camera(cam, C);
+  const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
+  const size_t npix = (size_t)R.width * R.height;
+  const size_t need = npix * 3 * sizeof(float) * (size_t)R.n_chunks;
+  if (ctx->partial_bytes < need) {
+    HIPCHK(hipStreamSynchronize(stream));
+    if (ctx->d_partial) HIPCHK(hipFree(ctx->d_partial));
+    ctx->d_partial = nullptr;
+    ctx->partial_bytes = 0;
+    HIPCHK(hipMalloc(&ctx->d_partial, need));
+    ctx->partial_bytes = need;
+  }
+  HIPCHK(hipMemsetAsync(ctx->d_queue, 0, 256, stream));
+  HIPCHK(hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (2 + RT_EV_COUNT), stream));
+  // persistent grid: as many workgroups as stay resident, never more than there is work for
+  int grid = ctx->n_cu * sc->blocks_per_cu[count ? 1 : 0];
+  int grid_needed = (R.n_items + RT_BLOCK - 1) / RT_BLOCK;
+  grid = std::max(1, std::min(grid, grid_needed));
+  if (stats) HIPCHK(hipEventRecord(ctx->ev0, stream));
+  if (R.n_items > 0)
+    HIPCHK(launch_render(sc->S, C, R, ctx->d_partial, ctx->d_queue, ctx->d_stats, count, grid, stream));
+  if (stats) HIPCHK(hipEventRecord(ctx->ev1, stream));
+  if (d_rgb_sum || d_argb) HIPCHK(launch_resolve(R, ctx->d_partial, d_rgb_sum, d_argb, stream));
+  if (stats) {
+    unsigned long long h[2 + RT_EV_COUNT];
+    HIPCHK(hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    std::memset(stats, 0, sizeof *stats);
+    stats->samples = h[0];
+    stats->rays = h[1];
+    for (int e = 0; e < RT_EV_COUNT; ++e) stats->events[e] = h[2 + e];
+    stats->kernel_ms = ms;
+  }
+  return RT_OK;
+}
+
+int rt_render(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, float* rgb_sum,
+              uint32_t* argb, rt_stats* stats) {
+  if (!ctx || !p) return fail(RT_ERR_ARG, "ctx or params is NULL");
+  if (p->width <= 0 || p->height <= 0 || (long long)p->width * p->height > (1ll << 28))
+    return fail(RT_ERR_ARG, "image size %dx%d out of range", p->width, p->height);
+  HIPCHK(hipSetDevice(ctx->device));
+  size_t npix = (size_t)p->width * p->height;
+  size_t rgb_bytes = npix * 3 * sizeof(float), argb_bytes = npix * sizeof(uint32_t);
+  int rc = ensure_io(ctx, rgb_bytes + argb_bytes);
+  if (rc) return rc;
+  float* d_rgb = static_cast<float*>(ctx->d_io);
+  uint32_t* d_argb = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->d_io) + rgb_bytes);
+  rc = rt_render_device(ctx, sc, cam, p, rgb_sum ? d_rgb : nullptr, argb ? d_argb : nullptr, stats, nullptr);
+  if (rc) return rc;
+  if (rgb_sum) HIPCHK(hipMemcpy(rgb_sum, d_rgb, rgb_bytes, hipMemcpyDeviceToHost));
+  if (argb) HIPCHK(hipMemcpy(argb, d_argb, argb_bytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipDeviceSynchronize());
+  return RT_OK;
+}
+
+int rt_tonemap_device(rt_ctx* ctx, const float* d_rgb_sum, int32_t n_pixels, int32_t spp_total, uint32_t* d_argb,
+                      void* hip_stream) {
+  if (!ctx || !d_rgb_sum || !d_argb || n_pixels <= 0 || spp_total <= 0) return fail(RT_ERR_ARG, "bad tonemap arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(launch_tonemap(d_rgb_sum, n_pixels, spp_total, d_argb, static_cast<hipStream_t>(hip_stream)));
+  return RT_OK;
+}
+
+int rt_hit_batch(rt_ctx* ctx, const rt_scene* sc, int32_t n, const float* orig3, const float* dir3, const float* time,
+                 float t_min, float t_max, const float* medium_xi, rt_hit* out) {
+  if (!ctx || !sc || sc->ctx != ctx) return fail(RT_ERR_ARG, "ctx/scene is NULL or the scene belongs to another context");
+  if (n < 0 || (n > 0 && (!orig3 || !dir3 || !out))) return fail(RT_ERR_ARG, "bad ray batch arguments");
+  if (n == 0) return RT_OK;
+  if (sc->has_time_bounds) {
+    for (int i = 0; i < n; ++i) {
+      float t = time ? time[i] : 0.f;
+      if (!(t >= sc->time_lo && t <= sc->time_hi))
+        return fail(RT_ERR_ARG, "ray %d: time %g outside [%g, %g]", i, t, sc->time_lo, sc->time_hi);
+    }
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  size_t b3 = (size_t)n * 3 * sizeof(float), b1 = (size_t)n * sizeof(float);
+  size_t bxi = medium_xi ? (size_t)n * std::max(sc->n_media, 1) * sizeof(float) : 0;
+  size_t bout = (size_t)n * sizeof(rt_hit);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  int rc = ensure_io(ctx, al(b3) * 2 + al(b1) + al(bxi) + al(bout));
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->d_io);
+  float* d_o = reinterpret_cast<float*>(base);
+  float* d_d = reinterpret_cast<float*>(base + al(b3));
+  float* d_t = reinterpret_cast<float*>(base + al(b3) * 2);
+  float* d_xi = reinterpret_cast<float*>(base + al(b3) * 2 + al(b1));
+  rt_hit* d_out = reinterpret_cast<rt_hit*>(base + al(b3) * 2 + al(b1) + al(bxi));
+  HIPCHK(hipMemcpy(d_o, orig3, b3, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_d, dir3, b3, hipMemcpyHostToDevice));
+  if (time) HIPCHK(hipMemcpy(d_t, time, b1, hipMemcpyHostToDevice));
+  if (medium_xi && sc->n_media > 0) HIPCHK(hipMemcpy(d_xi, medium_xi, (size_t)n * sc->n_media * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(launch_hit_batch(sc->S, n, d_o, d_d, time ? d_t : nullptr, t_min, t_max, medium_xi ? d_xi : nullptr, d_out, 0));
+  HIPCHK(hipMemcpy(out, d_out, bout, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_sample_batch(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, int32_t n,
+                    const int32_t* px, const int32_t* smp, float* out_rgb) {
+  if (!ctx || !sc || sc->ctx != ctx) return fail(RT_ERR_ARG, "ctx/scene is NULL or the scene belongs to another context");
+  DRender R;
+  int rc = fill_render(sc, cam, p, R);
+  if (rc) return rc;
+  if (n < 0 || (n > 0 && (!px || !smp || !out_rgb))) return fail(RT_ERR_ARG, "bad sample batch arguments");
+  if (n == 0) return RT_OK;
+  for (int i = 0; i < n; ++i)
+    if (px[i] < 0 || px[i] >= R.width * R.height || smp[i] < 0) return fail(RT_ERR_ARG, "sample %d: pixel or sample index out of range", i);
+  HIPCHK(hipSetDevice(ctx->device));
+  DCamera C;
+  fill_camera(cam, C);
+  size_t bi = (size_t)n * sizeof(int32_t), bo = (size_t)n * 3 * sizeof(float);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  rc = ensure_io(ctx, al(bi) * 2 + al(bo));
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->d_io);
+  int* d_px = reinterpret_cast<int*>(base);
+  int* d_smp = reinterpret_cast<int*>(base + al(bi));
+  float* d_out = reinterpret_cast<float*>(base + al(bi) * 2);
+  HIPCHK(hipMemcpy(d_px, px, bi, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_smp, smp, bi, hipMemcpyHostToDevice));
+  HIPCHK(launch_sample_batch(sc->S, C, R, n, d_px, d_smp, d_out, 0));
+  HIPCHK(hipMemcpy(out_rgb, d_out, bo, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+}  // extern "C"

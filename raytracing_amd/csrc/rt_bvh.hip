@@ -1,0 +1,254 @@
+// rt_bvh.hip — GPU construction of the bounding-volume hierarchy of one primitive group.
+//
+// The reference builds its BvhNode trees on the host by random-axis median splits
+// (base.clj:137-164) and its RotateY/Translate bounding boxes are unusable (rotate.clj:72-80,
+// translate.clj:18-21). Closest-hit results do not depend on the tree shape, so the device
+// builds its own: Morton codes of primitive centroids, a bitonic sort, Karras' parallel radix
+// tree ("Maximizing parallelism in the construction of BVHs, octrees, and k-d trees", HPG 2012)
+// and a bottom-up box fit done as one kernel launch per tree level (kernel boundaries give the
+// cross-workgroup visibility a single-launch atomic scheme would have to fence for).
+#include <hip/hip_runtime.h>
+
+#include "rt_launch.h"
+
+namespace rt {
+namespace {
+
+struct Box {
+  float mn[3], mx[3];
+};
+
+__device__ __forceinline__ void prim_box(const DPrim& P, float time_lo, float time_hi, Box& b) {
+  if (P.type == RT_PRIM_SPHERE || P.type == RT_PRIM_MOVING_SPHERE) {
+    double r = fabs(P.type == RT_PRIM_SPHERE ? P.d[3] : P.d[8]);
+    double c0[3], c1[3];
+    if (P.type == RT_PRIM_SPHERE) {
+      for (int a = 0; a < 3; ++a) c0[a] = c1[a] = P.d[a];
+    } else {  // the centre is linear in time (base.clj:298-302): bound its two extreme positions
+      double k0 = ((double)time_lo - P.d[6]) / (P.d[7] - P.d[6]);
+      double k1 = ((double)time_hi - P.d[6]) / (P.d[7] - P.d[6]);
+      for (int a = 0; a < 3; ++a) {
+        c0[a] = P.d[a] + (P.d[3 + a] - P.d[a]) * k0;
+        c1[a] = P.d[a] + (P.d[3 + a] - P.d[a]) * k1;
+      }
+    }
+    for (int a = 0; a < 3; ++a) {
+      b.mn[a] = (float)(fmin(c0[a], c1[a]) - r);
+      b.mx[a] = (float)(fmax(c0[a], c1[a]) + r);
+    }
+  } else {
+    int ia, ib, ic;
+    if (P.type == RT_PRIM_XY_RECT) { ia = 0; ib = 1; ic = 2; }
+    else if (P.type == RT_PRIM_XZ_RECT) { ia = 0; ib = 2; ic = 1; }
+    else { ia = 1; ib = 2; ic = 0; }
+    b.mn[ia] = P.f[0]; b.mx[ia] = P.f[1];
+    b.mn[ib] = P.f[2]; b.mx[ib] = P.f[3];
+    b.mn[ic] = P.f[4]; b.mx[ic] = P.f[4];
+  }
+}
+
+__global__ void k_prim_boxes(const DPrim* __restrict__ prims, int first, int n, float time_lo, float time_hi,
+                             Box* __restrict__ boxes) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Box b;
+  prim_box(prims[first + i], time_lo, time_hi, b);
+  boxes[i] = b;
+}
+
+// One block: bounds of all centroids and the largest absolute coordinate, then pad every box.
+__global__ void k_scene_bounds(Box* __restrict__ boxes, int n, float* __restrict__ out7) {
+  __shared__ float smin[3][256], smax[3][256], sext[256];
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f}, ext = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int a = 0; a < 3; ++a) {
+      float c = 0.5f * (boxes[i].mn[a] + boxes[i].mx[a]);
+      mn[a] = fminf(mn[a], c);
+      mx[a] = fmaxf(mx[a], c);
+      ext = fmaxf(ext, fmaxf(fabsf(boxes[i].mn[a]), fabsf(boxes[i].mx[a])));
+    }
+  }
+  for (int a = 0; a < 3; ++a) { smin[a][threadIdx.x] = mn[a]; smax[a][threadIdx.x] = mx[a]; }
+  sext[threadIdx.x] = ext;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      for (int a = 0; a < 3; ++a) {
+        smin[a][threadIdx.x] = fminf(smin[a][threadIdx.x], smin[a][threadIdx.x + s]);
+        smax[a][threadIdx.x] = fmaxf(smax[a][threadIdx.x], smax[a][threadIdx.x + s]);
+      }
+      sext[threadIdx.x] = fmaxf(sext[threadIdx.x], sext[threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    for (int a = 0; a < 3; ++a) { out7[a] = smin[a][0]; out7[3 + a] = smax[a][0]; }
+    out7[6] = sext[0];
+  }
+}
+
+// Boxes are padded by 2^-18 of the group's largest coordinate: the FP32 slab test and the FP32 /
+// FP64 primitive tests round differently, and a primitive must never be culled by its own box.
+__global__ void k_pad_boxes(Box* __restrict__ boxes, int n, const float* __restrict__ bounds7) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float pad = bounds7[6] * 3.814697265625e-6f + 1e-30f;
+  for (int a = 0; a < 3; ++a) { boxes[i].mn[a] -= pad; boxes[i].mx[a] += pad; }
+}
+
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {  // 10 bits -> every third bit
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+__global__ void k_morton(const Box* __restrict__ boxes, int n, int n_pad, const float* __restrict__ bounds7,
+                         unsigned long long* __restrict__ keys) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  if (i >= n) { keys[i] = ~0ull; return; }
+  uint32_t q[3];
+  for (int a = 0; a < 3; ++a) {
+    float lo = bounds7[a], hi = bounds7[3 + a];
+    float c = 0.5f * (boxes[i].mn[a] + boxes[i].mx[a]);
+    float u = (hi > lo) ? (c - lo) / (hi - lo) : 0.f;
+    q[a] = (uint32_t)fminf(fmaxf(u * 1024.f, 0.f), 1023.f);
+  }
+  uint32_t code = (expand_bits(q[0]) << 2) | (expand_bits(q[1]) << 1) | expand_bits(q[2]);
+  keys[i] = ((unsigned long long)code << 32) | (unsigned long long)(uint32_t)i;
+}
+
+__global__ void k_bitonic(unsigned long long* __restrict__ keys, int n_pad, int j, int k) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  int ixj = i ^ j;
+  if (ixj > i) {
+    unsigned long long a = keys[i], b = keys[ixj];
+    bool up = (i & k) == 0;
+    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+  }
+}
+
+__device__ __forceinline__ int delta(const unsigned long long* keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  return __clzll((long long)(keys[i] ^ keys[j]));  // keys are unique (the index is in the low word)
+}
+
+// Karras 2012, Algorithm 1 body: children and parent links of internal node i.
+__global__ void k_radix_tree(const unsigned long long* __restrict__ keys, int n, int first, int node_base,
+                             DBvhNode* __restrict__ nodes) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2)
+    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  int j = i + l * d;
+  int dnode = delta(keys, n, i, j);
+  int s = 0;
+  int t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  int gamma = i + s * d + min(d, 0);
+  int lo = min(i, j), hi = max(i, j);
+  DBvhNode* N = &nodes[node_base + i];
+  // a child range of one key is a leaf: the primitive whose group-local index is the key's low word
+  N->left = (lo == gamma) ? ~(first + (int)(uint32_t)keys[gamma]) : node_base + gamma;
+  N->right = (hi == gamma + 1) ? ~(first + (int)(uint32_t)keys[gamma + 1]) : node_base + gamma + 1;
+  N->pad[0] = N->pad[1] = 0;
+}
+
+// One level of the bottom-up fit. ready[i] = number of the pass that completed node i (0 = not
+// yet); a child counts as ready only if an EARLIER launch completed it, so every box a node
+// reads was written before the kernel boundary. height[i] = levels below node i.
+__global__ void k_fit_pass(const Box* __restrict__ boxes, int n, int first, int node_base,
+                           DBvhNode* __restrict__ nodes, int* __restrict__ ready, int* __restrict__ height,
+                           int pass) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1 || ready[i] != 0) return;
+  DBvhNode* N = &nodes[node_base + i];
+  const int child[2] = {N->left, N->right};
+  Box cb[2];
+  int ch[2];
+  for (int c = 0; c < 2; ++c) {
+    if (child[c] < 0) {
+      cb[c] = boxes[(~child[c]) - first];
+      ch[c] = 0;
+    } else {
+      int ci = child[c] - node_base;
+      int rp = ready[ci];
+      if (rp == 0 || rp >= pass) return;
+      const DBvhNode* C = &nodes[child[c]];
+      for (int a = 0; a < 3; ++a) {
+        cb[c].mn[a] = fminf(C->lmin[a], C->rmin[a]);
+        cb[c].mx[a] = fmaxf(C->lmax[a], C->rmax[a]);
+      }
+      ch[c] = height[ci];
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    N->lmin[a] = cb[0].mn[a]; N->lmax[a] = cb[0].mx[a];
+    N->rmin[a] = cb[1].mn[a]; N->rmax[a] = cb[1].mx[a];
+  }
+  height[i] = 1 + max(ch[0], ch[1]);
+  ready[i] = pass;
+}
+
+}  // namespace
+
+#define BVH_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return e_; } } while (0)
+
+hipError_t build_bvh(const DPrim* d_prims, int first, int n, DBvhNode* d_nodes, int node_base, float time_lo,
+                     float time_hi, int* height_out, hipStream_t stream) {
+  if (n < 2) return hipErrorInvalidValue;
+  int n_pad = 1;
+  while (n_pad < n) n_pad <<= 1;
+  Box* boxes = nullptr;
+  float* bounds = nullptr;
+  unsigned long long* keys = nullptr;
+  int *ready = nullptr, *height = nullptr;
+  auto cleanup = [&]() {
+    hipFree(boxes); hipFree(bounds); hipFree(keys); hipFree(ready); hipFree(height);
+  };
+  BVH_CHECK(hipMalloc(&boxes, sizeof(Box) * n));
+  BVH_CHECK(hipMalloc(&bounds, sizeof(float) * 8));
+  BVH_CHECK(hipMalloc(&keys, sizeof(unsigned long long) * n_pad));
+  BVH_CHECK(hipMalloc(&ready, sizeof(int) * n));
+  BVH_CHECK(hipMalloc(&height, sizeof(int) * n));
+  BVH_CHECK(hipMemsetAsync(ready, 0, sizeof(int) * n, stream));
+  BVH_CHECK(hipMemsetAsync(height, 0, sizeof(int) * n, stream));
+  const int B = 256;
+  hipLaunchKernelGGL(k_prim_boxes, dim3((n + B - 1) / B), dim3(B), 0, stream, d_prims, first, n, time_lo, time_hi, boxes);
+  hipLaunchKernelGGL(k_scene_bounds, dim3(1), dim3(256), 0, stream, boxes, n, bounds);
+  hipLaunchKernelGGL(k_morton, dim3((n_pad + B - 1) / B), dim3(B), 0, stream, boxes, n, n_pad, bounds, keys);
+  hipLaunchKernelGGL(k_pad_boxes, dim3((n + B - 1) / B), dim3(B), 0, stream, boxes, n, bounds);
+  for (int k = 2; k <= n_pad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1)
+      hipLaunchKernelGGL(k_bitonic, dim3((n_pad + B - 1) / B), dim3(B), 0, stream, keys, n_pad, j, k);
+  hipLaunchKernelGGL(k_radix_tree, dim3((n - 1 + B - 1) / B), dim3(B), 0, stream, keys, n, first, node_base, d_nodes);
+  BVH_CHECK(hipGetLastError());
+  int root_ready = 0;
+  int pass = 1;
+  const int max_pass = n + 2;  // a radix tree over n leaves is at most n-1 levels deep
+  while (!root_ready && pass <= max_pass) {
+    for (int rep = 0; rep < 8 && pass <= max_pass; ++rep, ++pass)
+      hipLaunchKernelGGL(k_fit_pass, dim3((n - 1 + B - 1) / B), dim3(B), 0, stream, boxes, n, first, node_base,
+                         d_nodes, ready, height, pass);
+    BVH_CHECK(hipMemcpyAsync(&root_ready, ready, sizeof(int), hipMemcpyDeviceToHost, stream));
+    BVH_CHECK(hipStreamSynchronize(stream));
+  }
+  if (!root_ready) { cleanup(); return hipErrorUnknown; }
+  BVH_CHECK(hipMemcpyAsync(height_out, height, sizeof(int), hipMemcpyDeviceToHost, stream));
+  BVH_CHECK(hipStreamSynchronize(stream));
+  cleanup();
+  return hipSuccess;
+}
+
+}  // namespace rt

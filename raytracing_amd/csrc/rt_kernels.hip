@@ -1,0 +1,307 @@
+// rt_kernels.hip — the kernels of librtmi.so (gfx950).
+//
+//   k_render        the per-pixel sample loop of the reference (core.clj:96-120) as a persistent
+//                   path loop: every lane carries one path, regenerates it in place when it
+//                   ends, and pulls new (pixel, sample-chunk) work items through a wave-local
+//                   queue refilled with one atomic per 64 items; lanes needing work are ranked
+//                   with a ballot + mbcnt prefix count.
+//   k_resolve       sums the per-chunk partial sums in a fixed order and optionally applies the
+//                   pixel post-process (core.clj:106-108,118,121-122).
+//   k_tonemap       that post-process alone.
+//   k_hit_batch     closest-hit records for caller-supplied rays (parity hook).
+//   k_sample_batch  radiance of single (pixel, sample) units (parity hook).
+#include <hip/hip_runtime.h>
+
+#include "rt_device.hpp"
+#include "rt_launch.h"
+
+namespace rt {
+
+// Dynamic LDS layout shared by all kernels that shade:
+//   [0, n_perlin*4096)                 Perlin gradient vectors, float4 each
+//   [.., + n_perlin*768 rounded to 16) Perlin permutations, bytes
+//   [.., + blockDim*bvh_stack*4)       per-lane BVH stacks, entry e of lane l at e*blockDim + l
+__device__ __forceinline__ Ctx make_ctx(const DScene& S, unsigned char* lds) {
+  Ctx X;
+  X.S = S;
+  size_t vec_bytes = (size_t)S.n_perlin * 4096;
+  size_t perm_bytes = ((size_t)S.n_perlin * 768 + 15) & ~(size_t)15;
+  float4* lv = reinterpret_cast<float4*>(lds);
+  uint8_t* lp = lds + vec_bytes;
+  const float4* gv = reinterpret_cast<const float4*>(S.perlin_vec);
+  for (int i = threadIdx.x; i < S.n_perlin * 256; i += blockDim.x) lv[i] = gv[i];
+  for (int i = threadIdx.x; i < S.n_perlin * 768; i += blockDim.x) lp[i] = S.perlin_perm[i];
+  __syncthreads();
+  X.lds_perlin_vec = reinterpret_cast<const float*>(lv);
+  X.lds_perlin_perm = lp;
+  X.lds_stack = reinterpret_cast<int*>(lds + vec_bytes + perm_bytes) + threadIdx.x;
+  X.stack_stride = blockDim.x;
+  return X;
+}
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// One ray-color invocation (core.clj:19-30) for the lane's current path. Returns true when the
+// path ended; `L` is then the radiance of the whole path (throughput already applied).
+template <class T>
+__device__ __forceinline__ bool path_step(const Ctx& X, const DRender& R, Ray& ray, V3& beta, uint32_t& bounce,
+                                          const Rng& g, V3& L, T& tally) {
+  Rec rec;
+  if (!closest_hit(X, ray, 0.001f, __builtin_inff(), g, bounce, nullptr, false, false, rec, tally)) {
+    L = beta * mk(R.bg[0], R.bg[1], R.bg[2]);  // core.clj:30
+    tally.template add<RT_EV_THROUGHPUT>();
+    return true;
+  }
+  V3 attenuation, emitted;
+  if (scatter(X, rec, ray, g, bounce, attenuation, emitted, tally)) {
+    beta = beta * attenuation;  // core.clj:27
+    tally.template add<RT_EV_THROUGHPUT>();
+    ++bounce;
+    if ((int)bounce >= R.max_depth) {  // core.clj:20-21
+      L = mk(0.f, 0.f, 0.f);
+      return true;
+    }
+    return false;
+  }
+  L = beta * emitted;  // core.clj:29
+  tally.template add<RT_EV_THROUGHPUT>();
+  return true;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_render(DScene S, DCamera cam, DRender R, float* __restrict__ out,
+                                                     uint32_t* __restrict__ queue,
+                                                     unsigned long long* __restrict__ stats) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  Ctx X = make_ctx(S, lds);
+  Tally<COUNT> tally;
+  if constexpr (COUNT) tally.clear();
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const int npix = R.width * R.height;
+  const int items_per_chunk = R.n_owned_tiles * 64;
+
+  // wave-uniform queue window [q_next, q_end) of work items taken from the global queue
+  uint32_t q_next = 0, q_end = 0;
+  bool q_dry = false;
+
+  // lane state
+  bool have_item = false, active = false, done = false;
+  int px = 0, py = 0, pix = 0, chunk_id = 0;
+  int s = 0, s_end = 0;
+  V3 acc = mk(0.f, 0.f, 0.f);
+  Ray ray{mk(0, 0, 0), mk(0, 0, 1), 0.f};
+  V3 beta = mk(1.f, 1.f, 1.f);
+  uint32_t bounce = 0;
+  Rng g{0u, 0u, R.seed_lo, R.seed_hi};
+  uint32_t n_rays = 0, n_samples = 0;
+
+  for (;;) {
+    bool need = !active && !done && !(have_item && s < s_end);
+    if (need && have_item) {
+      // core.clj:115-120 finished for this chunk: store the partial sum of its samples
+      size_t o = ((size_t)chunk_id * npix + pix) * 3;
+      out[o] = acc.x; out[o + 1] = acc.y; out[o + 2] = acc.z;
+      have_item = false;
+    }
+    unsigned long long mask = __ballot(need);
+    if (mask != 0ull) {  // wave-uniform
+      if (q_next == q_end && !q_dry) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(queue, (uint32_t)R.batch);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= (uint32_t)R.n_items) {
+          q_dry = true;
+        } else {
+          q_next = base;
+          q_end = min(base + (uint32_t)R.batch, (uint32_t)R.n_items);
+        }
+      }
+      uint32_t avail = q_end - q_next;
+      uint32_t cnt = (uint32_t)__popcll(mask);
+      if (need) {
+        uint32_t rank = lane_rank(mask);
+        if (rank < avail) {
+          uint32_t item = q_next + rank;
+          chunk_id = (int)(item / (uint32_t)items_per_chunk);
+          uint32_t rem = item - (uint32_t)chunk_id * (uint32_t)items_per_chunk;
+          int tile = R.shard_index + (int)(rem >> 6) * R.shard_count;
+          int in_tile = (int)(rem & 63u);
+          px = (tile % R.tiles_x) * RT_TILE + (in_tile & 7);
+          py = (tile / R.tiles_x) * RT_TILE + (in_tile >> 3);
+          if (px < R.width && py < R.height) {
+            pix = py * R.width + px;
+            s = chunk_id * R.chunk;
+            s_end = min(R.spp, s + R.chunk);
+            acc = mk(0.f, 0.f, 0.f);
+            have_item = true;
+          }
+        } else if (q_dry || avail == 0) {
+          if (q_dry) done = true;
+        }
+      }
+      q_next += min(cnt, avail);
+    }
+    if (!active && have_item && s < s_end) {
+      // core.clj:96-105: a fresh camera path for sample s of this pixel
+      g.k0 = (uint32_t)pix;
+      g.k1 = (uint32_t)(R.sample_offset + s);
+      ++s;
+      ++n_samples;
+      if (R.max_depth <= 0) {
+        tally.template add<RT_EV_ACCUMULATE>();
+      } else {
+        ray = camera_ray(cam, R, px, py, g, tally);
+        beta = mk(1.f, 1.f, 1.f);
+        bounce = 0;
+        active = true;
+      }
+    }
+    if (__ballot(!done) == 0ull) break;
+    if (active) {
+      V3 L;
+      ++n_rays;
+      if (path_step(X, R, ray, beta, bounce, g, L, tally)) {
+        acc = acc + L;  // core.clj:120
+        tally.template add<RT_EV_ACCUMULATE>();
+        active = false;
+      }
+    }
+  }
+  atomicAdd(&stats[0], (unsigned long long)n_samples);
+  atomicAdd(&stats[1], (unsigned long long)n_rays);
+  if constexpr (COUNT) {
+#pragma unroll
+    for (int e = 0; e < RT_EV_COUNT; ++e)
+      if (tally.ev[e]) atomicAdd(&stats[2 + e], (unsigned long long)tally.ev[e]);
+  }
+}
+
+// Sums the chunk partials of every pixel in chunk order (a fixed order, so the sum does not
+// depend on which wave rendered which chunk), writes 0 for pixels of other shards.
+__global__ void k_resolve(DRender R, const float* __restrict__ partial, float* __restrict__ rgb_sum,
+                          uint32_t* __restrict__ argb) {
+  int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  int npix = R.width * R.height;
+  if (pix >= npix) return;
+  int x = pix % R.width, y = pix / R.width;
+  int tile = (y / RT_TILE) * R.tiles_x + (x / RT_TILE);
+  float r = 0.f, g = 0.f, b = 0.f;
+  if (tile % R.shard_count == R.shard_index) {
+    for (int c = 0; c < R.n_chunks; ++c) {
+      size_t o = ((size_t)c * npix + pix) * 3;
+      r += partial[o]; g += partial[o + 1]; b += partial[o + 2];
+    }
+  }
+  if (rgb_sum) { rgb_sum[3 * (size_t)pix] = r; rgb_sum[3 * (size_t)pix + 1] = g; rgb_sum[3 * (size_t)pix + 2] = b; }
+  if (argb) argb[pix] = pack_pixel(r, g, b, R.spp);
+}
+
+__global__ void k_tonemap(const float* __restrict__ rgb_sum, int n_pixels, int spp, uint32_t* __restrict__ argb) {
+  int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= n_pixels) return;
+  argb[pix] = pack_pixel(rgb_sum[3 * (size_t)pix], rgb_sum[3 * (size_t)pix + 1], rgb_sum[3 * (size_t)pix + 2], spp);
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_hit_batch(DScene S, int n, const float* __restrict__ orig3,
+                                                        const float* __restrict__ dir3,
+                                                        const float* __restrict__ time, float tmin, float tmax,
+                                                        const float* __restrict__ medium_xi, rt_hit* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  Ctx X = make_ctx(S, lds);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Ray r{mk(orig3[3 * i], orig3[3 * i + 1], orig3[3 * i + 2]), mk(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]),
+        time ? time[i] : 0.f};
+  Rng g{0u, 0u, 0u, 0u};
+  Tally<false> tally;
+  Rec rec;
+  rt_hit h;
+  h.t = 0.f; h.p[0] = h.p[1] = h.p[2] = 0.f; h.normal[0] = h.normal[1] = h.normal[2] = 0.f;
+  h.u = h.v = 0.f; h.front_face = 0; h.mat_id = 0; h.hit = 0;
+  if (closest_hit(X, r, tmin, tmax, g, 0, medium_xi ? medium_xi + (size_t)i * S.n_media : nullptr,
+                  medium_xi == nullptr, true, rec, tally)) {
+    h.t = rec.t;
+    h.p[0] = rec.p.x; h.p[1] = rec.p.y; h.p[2] = rec.p.z;
+    h.normal[0] = rec.n.x; h.normal[1] = rec.n.y; h.normal[2] = rec.n.z;
+    h.u = rec.u; h.v = rec.v;
+    h.front_face = rec.front ? 1 : 0;
+    h.mat_id = rec.mat;
+    h.hit = 1;
+  }
+  out[i] = h;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_sample_batch(DScene S, DCamera cam, DRender R, int n,
+                                                           const int* __restrict__ px, const int* __restrict__ smp,
+                                                           float* __restrict__ out_rgb) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  Ctx X = make_ctx(S, lds);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Tally<false> tally;
+  Rng g{(uint32_t)px[i], (uint32_t)smp[i], R.seed_lo, R.seed_hi};
+  V3 L = mk(0.f, 0.f, 0.f);
+  if (R.max_depth > 0) {
+    Ray ray = camera_ray(cam, R, px[i] % R.width, px[i] / R.width, g, tally);
+    V3 beta = mk(1.f, 1.f, 1.f);
+    uint32_t bounce = 0;
+    while (!path_step(X, R, ray, beta, bounce, g, L, tally)) {}
+  }
+  out_rgb[3 * i] = L.x; out_rgb[3 * i + 1] = L.y; out_rgb[3 * i + 2] = L.z;
+}
+
+// ------------------------------------------------------------------------------ launchers
+size_t shade_lds_bytes(const DScene& S, int block) {
+  size_t vec_bytes = (size_t)S.n_perlin * 4096;
+  size_t perm_bytes = ((size_t)S.n_perlin * 768 + 15) & ~(size_t)15;
+  return vec_bytes + perm_bytes + (size_t)block * (size_t)S.bvh_stack * 4;
+}
+
+hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, float* out, uint32_t* queue,
+                         unsigned long long* stats, bool count, int grid, hipStream_t stream) {
+  size_t lds = shade_lds_bytes(S, RT_BLOCK);
+  if (count)
+    hipLaunchKernelGGL(k_render<true>, dim3(grid), dim3(RT_BLOCK), lds, stream, S, cam, R, out, queue, stats);
+  else
+    hipLaunchKernelGGL(k_render<false>, dim3(grid), dim3(RT_BLOCK), lds, stream, S, cam, R, out, queue, stats);
+  return hipGetLastError();
+}
+
+hipError_t render_occupancy(const DScene& S, bool count, int* blocks_per_cu) {
+  size_t lds = shade_lds_bytes(S, RT_BLOCK);
+  if (count) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render<true>, RT_BLOCK, lds);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render<false>, RT_BLOCK, lds);
+}
+
+hipError_t launch_resolve(const DRender& R, const float* partial, float* rgb_sum, uint32_t* argb,
+                          hipStream_t stream) {
+  int npix = R.width * R.height;
+  hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, stream, R, partial, rgb_sum, argb);
+  return hipGetLastError();
+}
+
+hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t* argb, hipStream_t stream) {
+  hipLaunchKernelGGL(k_tonemap, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, rgb_sum, n_pixels, spp, argb);
+  return hipGetLastError();
+}
+
+hipError_t launch_hit_batch(const DScene& S, int n, const float* orig3, const float* dir3, const float* time,
+                            float tmin, float tmax, const float* medium_xi, rt_hit* out, hipStream_t stream) {
+  size_t lds = shade_lds_bytes(S, RT_BLOCK);
+  hipLaunchKernelGGL(k_hit_batch, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds, stream, S, n, orig3,
+                     dir3, time, tmin, tmax, medium_xi, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_sample_batch(const DScene& S, const DCamera& cam, const DRender& R, int n, const int* px,
+                               const int* smp, float* out_rgb, hipStream_t stream) {
+  size_t lds = shade_lds_bytes(S, RT_BLOCK);
+  hipLaunchKernelGGL(k_sample_batch, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds, stream, S, cam, R, n,
+                     px, smp, out_rgb);
+  return hipGetLastError();
+}
+
+}  // namespace rt

@@ -1,0 +1,33 @@
+// rt_launch.h — host-callable launch wrappers around the kernels (internal to librtmi.so).
+#ifndef RT_LAUNCH_H
+#define RT_LAUNCH_H
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/rtmi.h"
+#include "rt_scene.h"
+
+#define RT_BLOCK 256  // threads per workgroup of the path kernels (4 waves)
+
+namespace rt {
+
+size_t shade_lds_bytes(const DScene& S, int block);
+hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, float* out, uint32_t* queue,
+                         unsigned long long* stats, bool count, int grid, hipStream_t stream);
+hipError_t render_occupancy(const DScene& S, bool count, int* blocks_per_cu);
+hipError_t launch_resolve(const DRender& R, const float* partial, float* rgb_sum, uint32_t* argb,
+                          hipStream_t stream);
+hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t* argb, hipStream_t stream);
+hipError_t launch_hit_batch(const DScene& S, int n, const float* orig3, const float* dir3, const float* time,
+                            float tmin, float tmax, const float* medium_xi, rt_hit* out, hipStream_t stream);
+hipError_t launch_sample_batch(const DScene& S, const DCamera& cam, const DRender& R, int n, const int* px,
+                               const int* smp, float* out_rgb, hipStream_t stream);
+
+// Builds a BVH over prims[first, first+n) on the GPU (n >= 2). Writes n-1 nodes to
+// nodes[node_base, node_base+n-1); the root is nodes[node_base]. time_lo/time_hi bound the ray
+// times moving spheres must be enclosed for. Returns the tree height in *height.
+hipError_t build_bvh(const DPrim* d_prims, int first, int n, DBvhNode* d_nodes, int node_base, float time_lo,
+                     float time_hi, int* height, hipStream_t stream);
+
+}  // namespace rt
+#endif

@@ -1,0 +1,129 @@
+// rt_scene.h — device-side scene layout shared by the host uploader and the kernels.
+//
+// The flat description of include/rtmi.h keeps the reference's hittable tree. The uploader
+// rewrites it into the form the kernels traverse:
+//   * every Translate / RotateY wrapper path from the root becomes an interned "chain" of
+//     operations (outermost first). The record transform of RotateY is not the inverse of its
+//     ray transform (reference rotate.clj:32-42), so chains are kept as operation lists and
+//     never collapsed into a matrix.
+//   * all leaves reachable under one chain form a "group": a contiguous run of primitive
+//     records in the reference's scan order (so the index doubles as the tie-break rank),
+//     intersected by a wave-uniform brute-force loop when small and by a GPU-built BVH
+//     otherwise.
+//   * every ConstantMedium becomes a medium record pointing at the groups of its boundary.
+#ifndef RT_SCENE_H
+#define RT_SCENE_H
+
+#include <stdint.h>
+
+#define RT_MAX_CHAIN_OPS 4     // deepest Translate/RotateY nesting supported
+#define RT_BRUTE_MAX 16        // groups up to this size skip the BVH
+#define RT_MAX_PERLIN_LDS 8    // Perlin table sets staged in LDS
+#define RT_TILE 8              // pixels per tile edge; one wave64 = one 8x8 tile
+
+enum { DOP_TRANSLATE = 0, DOP_ROTATE_Y = 1 };
+
+// 80 bytes. Spheres are intersected in FP64 (|oc|^2 - r^2 cancels catastrophically in FP32 for
+// the r = 1000 ground spheres), rectangles in FP32.
+struct DPrim {
+  int32_t type;  // RT_PRIM_*
+  int32_t mat;   // material index of the description
+  union {
+    double d[9];  // sphere: cx cy cz r | moving sphere: c0 xyz, c1 xyz, t0, t1, r
+    float f[18];  // rect: a0 a1 b0 b1 k
+  };
+};
+
+struct DChainOp {
+  int32_t kind;
+  float a, b, c;  // TRANSLATE: offset xyz | ROTATE_Y: sin, cos
+};
+
+struct DChain {
+  int32_t first_op, n_ops;
+};
+
+struct DGroup {
+  int32_t chain;
+  int32_t first_prim, n_prims;
+  int32_t bvh_root;  // node index, or -1 for the brute-force loop
+};
+
+struct DMedium {
+  int32_t first_group, n_groups;  // boundary groups (indices into groups[])
+  int32_t outer_chain;            // chain the medium itself lives under
+  int32_t phase_mat;
+  float neg_inv_density;
+};
+
+// One BVH node holds the boxes of both children so a traversal step is one 64-byte fetch.
+// child < 0 encodes a leaf: primitive index = ~child (index into prims[]).
+struct DBvhNode {
+  float lmin[3], lmax[3];
+  float rmin[3], rmax[3];
+  int32_t left, right;
+  int32_t pad[2];
+};
+
+struct DMat {
+  int32_t type;  // RT_MAT_*
+  int32_t tex;
+  int32_t needs_uv;  // its texture (or a checker branch of it) reads u/v: image textures only
+  int32_t pad;
+  float r, g, b, x;  // metal: albedo rgb, fuzz | dielectric: r = ir
+};
+
+struct DTex {
+  int32_t type;  // RT_TEX_*
+  int32_t i0, i1;  // checker: odd, even | noise: perlin id, scale | image: image id
+  float r, g, b;   // solid colour
+};
+
+struct DImage {
+  int32_t w, h;
+  int32_t first_texel;  // into texels[] (RGBA8, top row first)
+  int32_t pad;
+};
+
+struct DScene {
+  const DPrim* prims;
+  const DGroup* groups;
+  const DChain* chains;
+  const DChainOp* ops;
+  const DMedium* media;
+  const DBvhNode* nodes;
+  const DMat* mats;
+  const DTex* texs;
+  const float* perlin_vec;       // n_perlin * 256 * 4 (xyz + pad)
+  const uint8_t* perlin_perm;    // n_perlin * 3 * 256
+  const DImage* images;
+  const uint32_t* texels;
+  int32_t n_surface_groups;      // groups [0, n_surface_groups) are tested for every ray
+  int32_t n_groups;
+  int32_t n_media;
+  int32_t n_perlin;
+  int32_t bvh_stack;             // entries per lane the traversal stack needs (0 = no BVH)
+  int32_t pad;
+};
+
+struct DCamera {  // the reference's camera map in FP64 (camera.clj:24-33)
+  double origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3];
+  double lens_radius, time0, time1;
+};
+
+struct DRender {
+  int32_t width, height;
+  int32_t spp, sample_offset;
+  int32_t max_depth;
+  int32_t shard_index, shard_count;
+  int32_t tiles_x, tiles_y;
+  int32_t n_owned_tiles;   // tiles this call renders
+  int32_t chunk;           // samples per work item
+  int32_t n_chunks;        // ceil(spp / chunk)
+  int32_t n_items;         // n_owned_tiles * 64 * n_chunks
+  int32_t batch;           // work items a wave takes from the global queue at once
+  float bg[3];
+  uint32_t seed_lo, seed_hi;
+};
+
+#endif  // RT_SCENE_H

@@ -1,0 +1,168 @@
+"""ctypes binding of librtmi.so (include/rtmi.h). There is no CPU path: if the shared library
+or a HIP device is missing, loading or `Context()` raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtmi.so")
+
+EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version", "rt_scene_create",
+           "rt_scene_destroy", "rt_scene_get_info", "rt_render", "rt_render_device",
+           "rt_tonemap_device", "rt_hit_batch", "rt_sample_batch"]
+
+_LIB = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"librtmi error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """dlopen librtmi.so and declare its prototypes. Raises if the library was not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
+                           "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    fp, ip, u32p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+    L.rt_init.argtypes = [C.c_int32, C.POINTER(vp)]
+    L.rt_shutdown.argtypes = [vp]
+    L.rt_shutdown.restype = None
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_abi_version.restype = C.c_int
+    L.rt_scene_create.argtypes = [vp, C.POINTER(abi.rt_scene_desc), C.POINTER(vp)]
+    L.rt_scene_destroy.argtypes = [vp]
+    L.rt_scene_destroy.restype = None
+    L.rt_scene_get_info.argtypes = [vp, C.POINTER(abi.rt_scene_info)]
+    L.rt_render.argtypes = [vp, vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), fp, u32p,
+                            C.POINTER(abi.rt_stats)]
+    L.rt_render_device.argtypes = [vp, vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), vp, vp,
+                                   C.POINTER(abi.rt_stats), vp]
+    L.rt_tonemap_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
+    L.rt_hit_batch.argtypes = [vp, vp, C.c_int32, fp, fp, fp, C.c_float, C.c_float, fp, C.POINTER(abi.rt_hit)]
+    L.rt_sample_batch.argtypes = [vp, vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), C.c_int32,
+                                  ip, ip, fp]
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(rc, load().rt_last_error().decode("utf-8", "replace"))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def stats_dict(st: abi.rt_stats) -> dict:
+    return dict(samples=int(st.samples), rays=int(st.rays), kernel_ms=float(st.kernel_ms),
+                events={n: int(st.events[i]) for i, n in enumerate(abi.RT_EVENT_NAMES)})
+
+
+class Context:
+    """One HIP device (rt_init / rt_shutdown)."""
+
+    def __init__(self, device_id: int = 0):
+        self._L = load()
+        self._h = C.c_void_p()
+        self.device_id = device_id
+        _check(self._L.rt_init(device_id, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._L.rt_shutdown(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def scene(self, flat) -> "Scene":
+        return Scene(self, flat)
+
+    def tonemap_device(self, d_rgb_sum_ptr: int, n_pixels: int, spp_total: int, d_argb_ptr: int, stream: int = 0):
+        _check(self._L.rt_tonemap_device(self._h, d_rgb_sum_ptr, n_pixels, spp_total, d_argb_ptr, stream or None))
+
+
+class Scene:
+    """An uploaded world (rt_scene_create / rt_scene_destroy)."""
+
+    def __init__(self, ctx: Context, flat):
+        self.ctx = ctx
+        self.flat = flat
+        self._L = ctx._L
+        self._h = C.c_void_p()
+        _check(self._L.rt_scene_create(ctx._h, C.byref(flat.desc), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._L.rt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> dict:
+        out = abi.rt_scene_info()
+        _check(self._L.rt_scene_get_info(self._h, C.byref(out)))
+        return {n: getattr(out, n) for n, _ in abi.rt_scene_info._fields_}
+
+    def render(self, cam: abi.rt_camera, params: abi.rt_params, want_rgb=True, want_argb=True, want_stats=True):
+        """Host-buffer render. -> (rgb_sum (H, W, 3) float32 with row 0 = bottom | None,
+        argb (H, W) uint32 | None, stats dict | None)."""
+        W, H = params.width, params.height
+        rgb = np.zeros((H, W, 3), dtype=np.float32) if want_rgb else None
+        argb = np.zeros((H, W), dtype=np.uint32) if want_argb else None
+        st = abi.rt_stats() if want_stats else None
+        _check(self._L.rt_render(self.ctx._h, self._h, C.byref(cam), C.byref(params), _fp(rgb),
+                                 argb.ctypes.data_as(C.POINTER(C.c_uint32)) if want_argb else None,
+                                 C.byref(st) if want_stats else None))
+        return rgb, argb, (stats_dict(st) if want_stats else None)
+
+    def render_device(self, cam, params, d_rgb_sum_ptr: int = 0, d_argb_ptr: int = 0, want_stats=False, stream: int = 0):
+        """Device-buffer render into raw device pointers (e.g. torch tensors' data_ptr())."""
+        st = abi.rt_stats() if want_stats else None
+        _check(self._L.rt_render_device(self.ctx._h, self._h, C.byref(cam), C.byref(params),
+                                        d_rgb_sum_ptr or None, d_argb_ptr or None,
+                                        C.byref(st) if want_stats else None, stream or None))
+        return stats_dict(st) if want_stats else None
+
+    def hit_batch(self, orig, dirs, time=None, t_min=0.001, t_max=float("inf"), medium_xi=None):
+        """-> structured array of rt_hit records."""
+        orig = np.ascontiguousarray(orig, dtype=np.float32)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32)
+        n = orig.shape[0]
+        tm = None if time is None else np.ascontiguousarray(time, dtype=np.float32)
+        xi = None if medium_xi is None else np.ascontiguousarray(medium_xi, dtype=np.float32)
+        out = (abi.rt_hit * max(n, 1))()
+        _check(self._L.rt_hit_batch(self.ctx._h, self._h, n, _fp(orig), _fp(dirs), _fp(tm), t_min, t_max,
+                                    _fp(xi), out))
+        dt = np.dtype([("t", "f4"), ("p", "f4", 3), ("normal", "f4", 3), ("u", "f4"), ("v", "f4"),
+                       ("front_face", "i4"), ("mat_id", "i4"), ("hit", "i4")])
+        return np.frombuffer(out, dtype=dt, count=n).copy()
+
+    def sample_batch(self, cam, params, px, smp):
+        px = np.ascontiguousarray(px, dtype=np.int32)
+        smp = np.ascontiguousarray(smp, dtype=np.int32)
+        out = np.zeros((px.shape[0], 3), dtype=np.float32)
+        _check(self._L.rt_sample_batch(self.ctx._h, self._h, C.byref(cam), C.byref(params), px.shape[0],
+                                       px.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       smp.ctypes.data_as(C.POINTER(C.c_int32)), _fp(out)))
+        return out
