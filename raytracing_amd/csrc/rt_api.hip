@@ -236,11 +236,9 @@ struct Flattener {
         }
         DChainOp op;
         std::memset(&op, 0, sizeof op);
-        if (d->node_kind[node] == RT_NODE_TRANSLATE) {
-          op.kind = DOP_TRANSLATE; op.a = (float)nd[0]; op.b = (float)nd[1]; op.c = (float)nd[2];
-        } else {
-          op.kind = DOP_ROTATE_Y; op.a = (float)nd[0]; op.b = (float)nd[1];
-        }
+        op.kind = d->node_kind[node] == RT_NODE_TRANSLATE ? DOP_TRANSLATE : DOP_ROTATE_Y;
+        op.da = nd[0]; op.db = nd[1]; op.dc = op.kind == DOP_TRANSLATE ? nd[2] : 0.0;
+        op.a = (float)op.da; op.b = (float)op.db; op.c = (float)op.dc;
         ops.push_back(op);
         walk(ni[0], intern(ops), sink, in_boundary);
         break;
@@ -402,13 +400,16 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   auto emit_groups = [&](const Sink& sink) {
     for (int chain : sink.chain_order) {
       const std::vector<int>& list = sink.prims.at(chain);
-      DGroup G{chain, (int)prims.size(), (int)list.size(), -1};
+      DGroup G;
+      std::memset(&G, 0, sizeof G);
+      G.chain = chain; G.first_prim = (int)prims.size(); G.n_prims = (int)list.size(); G.bvh_root = -1;
       for (int pi : list) {
         DPrim P;
         std::memset(&P, 0, sizeof P);
         P.type = d->prim_type[pi];
         P.mat = d->prim_mat[pi];
         const double* pd = d->prim_d + (size_t)pi * RT_PRIM_STRIDE;
+        if (P.type <= RT_PRIM_MOVING_SPHERE && chain != 0) G.flags |= DGROUP_SPHERES_UNDER_CHAIN;
         if (P.type == RT_PRIM_SPHERE) {
           for (int k = 0; k < 4; ++k) P.d[k] = pd[k];
         } else if (P.type == RT_PRIM_MOVING_SPHERE) {

@@ -137,7 +137,8 @@ struct Best {
 // Per (ray, group) constants.
 struct RayX {
   V3 o, d;
-  V3 inv;     // 1/d
+  V3 inv;        // 1/d
+  V3 o_lo, d_lo; // FP64 residuals of o and d (zero unless the group asks for an FP64 ray)
   float tm;
 };
 
@@ -145,8 +146,11 @@ RT_DEV RayX make_rayx(V3 o, V3 d, float tm) {
   RayX r;
   r.o = o; r.d = d; r.tm = tm;
   r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  r.o_lo = r.d_lo = mk(0.f, 0.f, 0.f);
   return r;
 }
+RT_DEV D3 rayx_o64(const RayX& r) { return mkd((double)r.o.x + (double)r.o_lo.x, (double)r.o.y + (double)r.o_lo.y, (double)r.o.z + (double)r.o_lo.z); }
+RT_DEV D3 rayx_d64(const RayX& r) { return mkd((double)r.d.x + (double)r.d_lo.x, (double)r.d.y + (double)r.d_lo.y, (double)r.d.z + (double)r.d_lo.z); }
 
 RT_DEV bool is_rect(int type) { return type >= RT_PRIM_XY_RECT; }
 
@@ -183,7 +187,7 @@ RT_DEV bool sphere_roots(const DPrim& P, const RayX& r, double& root1, double& r
   if (P.type == RT_PRIM_MOVING_SPHERE) tally.template add<RT_EV_MSPHERE_CENTER>();
   D3 c = sphere_center(P, r.tm);
   double radius = sphere_radius(P);
-  D3 o = tod(r.o), d = tod(r.d);
+  D3 o = rayx_o64(r), d = rayx_d64(r);
   D3 oc = mkd(o.x - c.x, o.y - c.y, o.z - c.z);
   double a = ddot(d, d);
   double half_b = ddot(oc, d);
@@ -260,6 +264,36 @@ RT_DEV void chain_apply(const DScene& S, int chain, V3& o, V3& d, T& tally) {
       tally.template add<RT_EV_ROTATE_RAY>();
     }
   }
+}
+
+// The ray of group g: its chain applied to the world ray. Groups with spheres below a chain get
+// the transform in FP64 (translate.clj:11, rotate.clj:18-27 on the exact FP32 world ray), split
+// into an FP32 value and an FP32 residual, so the FP64 sphere test sees what the reference sees.
+template <class T>
+RT_DEV RayX group_ray(const DScene& S, const DGroup& G, const Ray& wr, T& tally) {
+  if (!(G.flags & DGROUP_SPHERES_UNDER_CHAIN)) {
+    V3 o = wr.o, d = wr.d;
+    chain_apply(S, G.chain, o, d, tally);
+    return make_rayx(o, d, wr.tm);
+  }
+  D3 o = tod(wr.o), d = tod(wr.d);
+  const DChain C = S.chains[G.chain];
+  for (int i = 0; i < C.n_ops; ++i) {
+    const DChainOp op = S.ops[C.first_op + i];
+    if (op.kind == DOP_TRANSLATE) {
+      o = mkd(o.x - op.da, o.y - op.db, o.z - op.dc);
+      tally.template add<RT_EV_TRANSLATE_RAY>();
+    } else {
+      double s = op.da, c = op.db;
+      o = mkd(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
+      d = mkd(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
+      tally.template add<RT_EV_ROTATE_RAY>();
+    }
+  }
+  RayX r = make_rayx(tof(o), tof(d), wr.tm);
+  r.o_lo = mk((float)(o.x - (double)r.o.x), (float)(o.y - (double)r.o.y), (float)(o.z - (double)r.o.z));
+  r.d_lo = mk((float)(d.x - (double)r.d.x), (float)(d.y - (double)r.d.y), (float)(d.z - (double)r.d.z));
+  return r;
 }
 
 // ---------------------------------------------------------------------------------- BVH
@@ -382,11 +416,11 @@ RT_DEV void prim_record(const DScene& S, int prim, const RayX& r, float t, bool 
     double root = second_root ? root2 : root1;
     D3 c = sphere_center(P, r.tm);
     double inv_r = 1.0 / sphere_radius(P);
-    D3 pd = mkd((double)r.o.x + root * (double)r.d.x, (double)r.o.y + root * (double)r.d.y,
-                (double)r.o.z + root * (double)r.d.z);
+    D3 o64 = rayx_o64(r), d64 = rayx_d64(r);
+    D3 pd = mkd(o64.x + root * d64.x, o64.y + root * d64.y, o64.z + root * d64.z);
     D3 out = mkd((pd.x - c.x) * inv_r, (pd.y - c.y) * inv_r, (pd.z - c.z) * inv_r);
     if (want_uv) sphere_uv(out, rec.u, rec.v);
-    rec.front = ddot(tod(r.d), out) < 0.0;
+    rec.front = ddot(d64, out) < 0.0;
     rec.n = rec.front ? tof(out) : neg(tof(out));
     rec.p = tof(pd);
   }
@@ -446,17 +480,13 @@ RT_DEV bool medium_t(const Ctx& X, int m, const Ray& wr, float tmin, float tmax,
   Best b1{INF, -1, -1};
   for (int gi = 0; gi < M.n_groups; ++gi) {
     int gidx = M.first_group + gi;
-    V3 o = wr.o, d = wr.d;
-    chain_apply(S, S.groups[gidx].chain, o, d, tally);
-    group_hit(X, gidx, make_rayx(o, d, wr.tm), -INF, b1, tally);
+    group_hit(X, gidx, group_ray(S, S.groups[gidx], wr, tally), -INF, b1, tally);
   }
   if (b1.prim < 0) return false;
   Best b2{INF, -1, -1};
   for (int gi = 0; gi < M.n_groups; ++gi) {
     int gidx = M.first_group + gi;
-    V3 o = wr.o, d = wr.d;
-    chain_apply(S, S.groups[gidx].chain, o, d, tally);
-    group_hit(X, gidx, make_rayx(o, d, wr.tm), b1.t + 0.0001f, b2, tally);
+    group_hit(X, gidx, group_ray(S, S.groups[gidx], wr, tally), b1.t + 0.0001f, b2, tally);
   }
   if (b2.prim < 0) return false;
   float t1 = (b1.t < tmin) ? tmin : b1.t;
@@ -487,11 +517,8 @@ RT_DEV bool closest_hit(const Ctx& X, const Ray& wr, float tmin, float tmax, con
                         const float* medium_xi, bool skip_media, bool want_uv_always, Rec& rec, T& tally) {
   const DScene& S = X.S;
   Best best{tmax, -1, -1};
-  for (int gi = 0; gi < S.n_surface_groups; ++gi) {
-    V3 o = wr.o, d = wr.d;
-    chain_apply(S, S.groups[gi].chain, o, d, tally);
-    group_hit(X, gi, make_rayx(o, d, wr.tm), tmin, best, tally);
-  }
+  for (int gi = 0; gi < S.n_surface_groups; ++gi)
+    group_hit(X, gi, group_ray(S, S.groups[gi], wr, tally), tmin, best, tally);
   if (!skip_media) {
     for (int m = 0; m < S.n_media; ++m) {
       // the medium lives under its own outer chain; lengths and t are chain-invariant
@@ -510,9 +537,7 @@ RT_DEV bool closest_hit(const Ctx& X, const Ray& wr, float tmin, float tmax, con
     const bool second_root = (best.group & RT_SECOND_ROOT) != 0;
     best.group &= ~RT_SECOND_ROOT;
     int chain = S.groups[best.group].chain;
-    V3 o = wr.o, d = wr.d;
-    chain_apply(S, chain, o, d, tally);
-    RayX rx = make_rayx(o, d, wr.tm);
+    RayX rx = group_ray(S, S.groups[best.group], wr, tally);
     bool want_uv = want_uv_always || S.mats[S.prims[best.prim].mat].needs_uv != 0;
     prim_record(S, best.prim, rx, best.t, second_root, want_uv, rec, tally);
     chain_unwind(S, chain, wr.d, rec, tally);

@@ -36,7 +36,8 @@ struct DPrim {
 
 struct DChainOp {
   int32_t kind;
-  float a, b, c;  // TRANSLATE: offset xyz | ROTATE_Y: sin, cos
+  float a, b, c;     // TRANSLATE: offset xyz | ROTATE_Y: sin, cos
+  double da, db, dc; // the same in FP64, for groups whose spheres are intersected in FP64
 };
 
 struct DChain {
@@ -47,7 +48,11 @@ struct DGroup {
   int32_t chain;
   int32_t first_prim, n_prims;
   int32_t bvh_root;  // node index, or -1 for the brute-force loop
+  int32_t flags;     // DGROUP_*
+  int32_t pad[3];
 };
+#define DGROUP_SPHERES_UNDER_CHAIN 1  // spheres below a non-identity chain: the ray is carried into
+                                      // chain space in FP64 (as a float hi + lo pair)
 
 struct DMedium {
   int32_t first_group, n_groups;  // boundary groups (indices into groups[])

@@ -30,6 +30,13 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64/libhsa-runtime64. If it is
+    # going to be used in this process (device buffers, torch.distributed), it has to be loaded
+    # first so that librtmi.so binds to the same runtime; a second HSA runtime finds no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
                            "(there is no CPU fallback)")

@@ -1,0 +1,74 @@
+"""Error behaviour of the C ABI on the GPU box: bad arguments come back as codes + messages,
+never as crashes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, flatten, lib
+from raytracing_amd.hittables import (constant_medium, hittable_list, rotate_y, sphere, translate,
+                                      xy_rect, moving_sphere)
+from raytracing_amd.materials import lambertian
+from util import scene_bundle
+
+pytestmark = pytest.mark.gpu
+GREY = lambertian([0.5, 0.5, 0.5])
+
+
+def test_bad_render_arguments(gpu_ctx):
+    cfg, flat, cam = scene_bundle("cornell-box")
+    sc = gpu_ctx.scene(flat)
+    for kw in (dict(width=0), dict(spp=0), dict(shard_index=2, shard_count=2), dict(max_depth=-1),
+               dict(sample_offset=-1)):
+        args = dict(width=8, height=8, spp=1)
+        args.update(kw)
+        with pytest.raises(lib.RtError) as ei:
+            sc.render(cam, abi.make_params(**args))
+        assert ei.value.code == abi.RT_ERR_ARG
+    sc.close()
+
+
+def test_bad_scene_descriptions(gpu_ctx):
+    flat = flatten.flatten_world([sphere([0, 0, 0], 1, GREY)])
+    flat.a_prim_mat[0] = 7
+    with pytest.raises(lib.RtError) as ei:
+        gpu_ctx.scene(flat)
+    assert ei.value.code == abi.RT_ERR_ARG
+    flat = flatten.flatten_world([sphere([0, 0, 0], 1, GREY)])
+    flat.a_children[0] = flat.desc.root  # the world list contains itself
+    with pytest.raises(lib.RtError) as ei:
+        gpu_ctx.scene(flat)
+    assert "cycle" in str(ei.value)
+    deep = sphere([0, 0, 0], 1, GREY)
+    for _ in range(5):
+        deep = translate(deep, [1, 0, 0])
+    with pytest.raises(lib.RtError) as ei:
+        gpu_ctx.scene(flatten.flatten_world([deep]))
+    assert ei.value.code == abi.RT_ERR_UNSUPPORTED
+    nested = constant_medium(constant_medium(sphere([0, 0, 0], 1, GREY), 1.0, [1, 1, 1]), 1.0, [1, 1, 1])
+    with pytest.raises(lib.RtError) as ei:
+        gpu_ctx.scene(flatten.flatten_world([nested]))
+    assert ei.value.code == abi.RT_ERR_UNSUPPORTED
+
+
+def test_empty_world_and_zero_depth(gpu_ctx):
+    cfg, _, cam = scene_bundle("cornell-box")
+    sc = gpu_ctx.scene(flatten.flatten_world([]))
+    rgb, argb, st = sc.render(cam, abi.make_params(9, 5, 2, 50, (0.7, 0.8, 1.0)))
+    assert np.allclose(rgb, np.float32([1.4, 1.6, 2.0])) and st["rays"] == 90
+    rgb, argb, st = sc.render(cam, abi.make_params(9, 5, 2, 0, (0.7, 0.8, 1.0)))
+    assert (rgb == 0).all() and st["rays"] == 0 and st["samples"] == 90
+    assert (argb == 0xFF000000).all()
+    h = sc.hit_batch(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert len(h) == 0
+    sc.close()
+
+
+def test_shutter_outside_moving_sphere_bounds_is_rejected(gpu_ctx):
+    world = [moving_sphere([0, 0, 0], [1, 0, 0], 0, 1, 1, GREY)] + [sphere([i, 0, 5], 0.1, GREY) for i in range(20)]
+    sc = gpu_ctx.scene(flatten.flatten_world(world))
+    cfg, _, cam = scene_bundle("cornell-box")
+    cam.time1 = 2.0
+    with pytest.raises(lib.RtError):
+        sc.render(cam, abi.make_params(8, 8, 1))
+    sc.close()
