@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Cornell box 1024x1024 @ 1000 spp (BASELINE.json configs[3]), Msamples/s.
+
+A step = one complete render of that workload: every rank renders its tile shard (rank r owns
+the 8x8 tiles t with t % N == r), the per-GPU FP32 accumulators are summed onto rank 0 with one
+RCCL reduce and rank 0 packs the pixels. Inputs (the uploaded world, the camera) are resident in
+HBM before the timed region. Total work is fixed as N grows (strong scaling).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (before librtmi.so: one HIP runtime per process)
+import torch.distributed as dist  # noqa: E402
+
+from raytracing_amd import abi, lib  # noqa: E402
+from raytracing_amd.core import build_camera, setup  # noqa: E402
+from raytracing_amd.dist import render_distributed  # noqa: E402
+
+# Algorithmic FLOPs per event of the path kernel (add/sub/mul/div/sqrt/min/max/abs/floor and each
+# transcendental = 1, FMA = 2; compares, selects, integer and RNG work = 0), following the
+# reference's arithmetic with common subexpressions computed once.
+FLOPS_PER_EVENT = {
+    "aabb_test": 21, "sphere_test": 23, "sphere_root": 4, "sphere_record": 32, "msphere_center": 12,
+    "rect_test": 6, "rect_record": 20, "rotate_y_ray": 12, "rotate_y_rec": 20, "translate_ray": 3,
+    "translate_rec": 11, "medium_sample": 16, "camera_ray": 35, "unit_sphere_trial": 11,
+    "unit_disk_trial": 7, "lambert_scatter": 13, "metal_scatter": 33, "dielectric_scatter": 60,
+    "iso_scatter": 0, "light_emit": 0, "checker": 8, "perlin_noise": 250, "noise_tex": 41,
+    "image_tex": 10, "throughput_mul": 3, "accumulate": 3,
+}
+PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+
+
+def cpu_baseline(flat, cam, cfg, seconds=12.0):
+    """The C++ FP64 restatement of the reference path (oracle/), timed on this host's cores on a
+    bounded sample of the same workload: Cornell at 256x256, spp chosen for ~`seconds` of work."""
+    from oracle import binding as ob
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    W = H = 256
+    pilot = abi.make_params(64, 64, 8, 50, cfg["background"], seed=1)
+    t0 = time.perf_counter()
+    ob.render(flat, cam, pilot, nthreads=threads, want_argb=False)
+    rate = 64 * 64 * 8 / max(time.perf_counter() - t0, 1e-6)
+    spp = int(max(4, min(1000, seconds * rate / (W * H))))
+    p = abi.make_params(W, H, spp, 50, cfg["background"], seed=1)
+    t0 = time.perf_counter()
+    _, _, rays = ob.render(flat, cam, p, nthreads=threads, want_argb=False)
+    dt = time.perf_counter() - t0
+    return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"cornell-box {W}x{H} @{spp}spp depth 50 ({W * H * spp} samples, {dt:.1f} s), "
+                      "C++ FP64 restatement of the Clojure path, not the JVM",
+            "rays_per_sample": rays / (W * H * spp)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cornell-box")
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=1000)
+    ap.add_argument("--split", default="tile", choices=["tile", "sample"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg, flat = setup(args.scene, scene_seed=1)
+    cam = build_camera(cfg, args.width / args.height)
+    ctx = lib.Context(local_rank)
+    scene = ctx.scene(flat)
+    W, H, spp = args.width, args.height, args.spp
+    base = abi.make_params(W, H, spp, 50, cfg["background"], seed=0x5EED0001)
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device=device)
+    argb = torch.zeros((H, W), dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream(device)
+    kernel_ms, rays_total = [], []
+
+    def render_fn(p):
+        st = scene.render_device(cam, p, acc.data_ptr(), 0, want_stats=True, stream=stream.cuda_stream)
+        kernel_ms.append(st["kernel_ms"])
+        rays_total.append(st["rays"])
+        return acc
+
+    def step():
+        render_distributed(render_fn, base, rank, world, args.split)
+        if rank == 0:
+            ctx.tonemap_device(acc.data_ptr(), W * H, spp, argb.data_ptr(), stream.cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms.clear()
+    rays_total.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed, float(sum(kernel_ms)) / max(len(kernel_ms), 1), float(sum(rays_total))],
+                     dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, kern_ms_max, rays = float(tmax[0]), float(tmax[1]), float(tsum[2])
+    else:
+        kern_ms_max, rays = float(t[1]), float(t[2])
+
+    # Roofline numerator: event counts of the SAME kernel from its counting build (a separate,
+    # untimed launch at reduced spp; FLOP per sample does not depend on spp beyond MC noise).
+    count_spp = min(spp, 16)
+    cp = abi.make_params(W, H, count_spp, 50, cfg["background"], seed=0x5EED0001, shard_index=rank,
+                         shard_count=world, flags=abi.RT_FLAG_COUNTERS)
+    cst = scene.render_device(cam, cp, 0, 0, want_stats=True, stream=stream.cuda_stream)
+    flop = sum(FLOPS_PER_EVENT[k] * v for k, v in cst["events"].items())
+    flop_per_sample = flop / max(cst["samples"], 1)
+    fl = torch.tensor([flop, float(cst["samples"])], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(fl, op=dist.ReduceOp.SUM)
+        flop_per_sample = float(fl[0]) / max(float(fl[1]), 1.0)
+
+    if rank == 0:
+        samples_per_step = W * H * spp
+        value = samples_per_step * args.steps / elapsed / 1e6
+        # per-GPU kernel rate: this rank's share of the samples over its own kernel time
+        my_samples = samples_per_step / world
+        achieved = flop_per_sample * my_samples / (kern_ms_max * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_render_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples/s (whole node) Cornell 1024^2 @1000spp; % FP32 peak",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene} {W}x{H} @{spp}spp depth 50 (core.clj:52-59 constants, "
+                                   "reference cornell-box world)",
+                       "parallelism": f"{args.split}-shard x{world}" + (" + RCCL reduce(sum) to rank 0" if world > 1 else ""),
+                       "samples_per_step": samples_per_step},
+            "rays_per_sample": rays / (samples_per_step * args.steps),
+            "Mrays_per_s": rays / elapsed / 1e6,
+            "flop_per_sample": flop_per_sample,
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "kernel": "rt::k_render<false>", "kernel_ms": kern_ms_max,
+                         "note": "algorithmic FLOP per event x event counts of the counting build of the same "
+                                 "kernel, per GPU, over that GPU's HIP-event kernel time; the path is branchy "
+                                 "FP32 VALU work, neither HBM- nor MFMA-bound"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(flat, cam, cfg, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    scene.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
