@@ -1,0 +1,43 @@
+"""Condenses a tools/profile.sh output directory into a text summary (kernel stats + PMC sums
+for the path kernel)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+print("== kernel stats (rocprofv3 --kernel-trace --stats)")
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            print("  ", {k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+print("== per-dispatch (kernel trace): k_render<false> launches")
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if "k_render" in row.get("Kernel_Name", ""):
+                dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+                print("  ", row["Kernel_Name"][:60], "ms", round(dur, 3), "VGPR", row.get("VGPR_Count"), "SGPR", row.get("SGPR_Count"),
+                      "LDS", row.get("LDS_Block_Size"), "scratch", row.get("Scratch_Size"), "grid", row.get("Grid_Size"), "wg", row.get("Workgroup_Size"))
+print("== PMC counters summed over the k_render<false> dispatches (per launch = sum / launches)")
+sums = defaultdict(float)
+launches = defaultdict(set)
+for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if "k_renderILb0" in row.get("Kernel_Name", "") or "k_render<false>" in row.get("Kernel_Name", ""):
+                sums[row["Counter_Name"]] += float(row["Counter_Value"])
+                launches[row["Counter_Name"]].add(row["Dispatch_Id"])
+for k in sorted(sums):
+    n = max(len(launches[k]), 1)
+    print(f"   {k:28s} total {sums[k]:.6g}  launches {n}  per launch {sums[k] / n:.6g}")
+g = lambda k: sums.get(k, 0.0) / max(len(launches.get(k, [1])), 1)
+if g("SQ_INSTS_VALU"):
+    print("== derived (per launch)")
+    print(f"   active-lane ratio  SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64) = {g('SQ_THREAD_CYCLES_VALU') / max(g('SQ_ACTIVE_INST_VALU') * 64, 1):.4f}")
+    print(f"   VALU issue share   SQ_ACTIVE_INST_VALU*4 / SQ_BUSY_CYCLES           = {g('SQ_ACTIVE_INST_VALU') * 4 / max(g('SQ_BUSY_CYCLES'), 1):.4f}")
+    print(f"   waves {g('SQ_WAVES'):.0f}, VALU insts/wave {g('SQ_INSTS_VALU') / max(g('SQ_WAVES'), 1):.0f}, SALU insts/wave {g('SQ_INSTS_SALU') / max(g('SQ_WAVES'), 1):.0f}")
+if g("FETCH_SIZE") or g("WRITE_SIZE"):
+    print(f"   HBM read  (FETCH_SIZE KiB, gfx950 wide-read correction x2 NOT applied): {g('FETCH_SIZE'):.6g} KiB")
+    print(f"   HBM write (WRITE_SIZE KiB): {g('WRITE_SIZE'):.6g} KiB")
