@@ -397,6 +397,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   std::vector<DGroup> groups;
   bool any_moving = false;
   double tlo = 0.0, thi = 1.0;
+  uint32_t features = 0;  // F_* mask
   auto emit_groups = [&](const Sink& sink) {
     for (int chain : sink.chain_order) {
       const std::vector<int>& list = sink.prims.at(chain);
@@ -406,13 +407,15 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
       for (int pi : list) {
         DPrim P;
         std::memset(&P, 0, sizeof P);
-        P.type = d->prim_type[pi];
+        const int ptype = d->prim_type[pi];
+        P.type = ptype | ((int)groups.size() << 4);
         P.mat = d->prim_mat[pi];
         const double* pd = d->prim_d + (size_t)pi * RT_PRIM_STRIDE;
-        if (P.type <= RT_PRIM_MOVING_SPHERE && chain != 0) G.flags |= DGROUP_SPHERES_UNDER_CHAIN;
-        if (P.type == RT_PRIM_SPHERE) {
+        if (ptype <= RT_PRIM_MOVING_SPHERE) features |= F_SPHERES;
+        if (ptype <= RT_PRIM_MOVING_SPHERE && chain != 0) G.flags |= DGROUP_SPHERES_UNDER_CHAIN;
+        if (ptype == RT_PRIM_SPHERE) {
           for (int k = 0; k < 4; ++k) P.d[k] = pd[k];
-        } else if (P.type == RT_PRIM_MOVING_SPHERE) {
+        } else if (ptype == RT_PRIM_MOVING_SPHERE) {
           for (int k = 0; k < 9; ++k) P.d[k] = pd[k];
           any_moving = true;
           tlo = std::min(tlo, std::min(pd[6], pd[7]));
@@ -427,6 +430,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   };
   emit_groups(F.surface);
   int n_surface_groups = (int)groups.size();
+  if (F.chains.size() > (1u << 20)) return fail(RT_ERR_UNSUPPORTED, "too many distinct instance chains");
   std::vector<DMedium> media((size_t)d->n_media);
   for (int m = 0; m < d->n_media; ++m) {
     HostMedium& M = F.media[m];
@@ -457,8 +461,20 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
     std::memset(&M, 0, sizeof M);
     M.type = d->mat_type[i];
     M.tex = d->mat_tex[i];
-    M.needs_uv = tex_needs_uv(d, d->mat_tex[i]) ? 1 : 0;
+    M.flags = tex_needs_uv(d, d->mat_tex[i]) ? DMAT_NEEDS_UV : 0;
     M.r = (float)md[0]; M.g = (float)md[1]; M.b = (float)md[2]; M.x = (float)md[3];
+    const bool textured = M.type == RT_MAT_LAMBERTIAN || M.type == RT_MAT_DIFFUSE_LIGHT || M.type == RT_MAT_ISOTROPIC;
+    if (textured) {
+      if (d->tex_type[M.tex] == RT_TEX_SOLID) {
+        M.flags |= DMAT_SOLID;
+        const double* td = d->tex_d + (size_t)M.tex * RT_TEX_DSTRIDE;
+        M.r = (float)td[0]; M.g = (float)td[1]; M.b = (float)td[2];
+      } else {
+        features |= F_TEXTURES;
+      }
+    }
+    if (M.type == RT_MAT_METAL || M.type == RT_MAT_DIELECTRIC) features |= F_SPECULAR;
+    if (M.type == RT_MAT_ISOTROPIC) features |= F_MEDIA;
     mats[i] = M;
   }
   std::vector<DTex> texs((size_t)d->n_tex);
@@ -533,6 +549,10 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   }
   S.nodes = d_nodes;
   S.bvh_stack = n_bvh_nodes ? max_height + 1 : 0;
+  if (n_bvh_nodes) features |= F_BVH;
+  if (d->n_media) features |= F_MEDIA;
+  if (chains.size() > 1) features |= F_CHAINS;
+  S.features = features;
 
   if ((rc = upload(sc, groups, &S.groups))) return rc;
   if ((rc = upload(sc, chains, &S.chains))) return rc;

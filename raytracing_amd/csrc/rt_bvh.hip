@@ -19,10 +19,11 @@ struct Box {
 };
 
 __device__ __forceinline__ void prim_box(const DPrim& P, float time_lo, float time_hi, Box& b) {
-  if (P.type == RT_PRIM_SPHERE || P.type == RT_PRIM_MOVING_SPHERE) {
-    double r = fabs(P.type == RT_PRIM_SPHERE ? P.d[3] : P.d[8]);
+  const int type = P.type & 15;
+  if (type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE) {
+    double r = fabs(type == RT_PRIM_SPHERE ? P.d[3] : P.d[8]);
     double c0[3], c1[3];
-    if (P.type == RT_PRIM_SPHERE) {
+    if (type == RT_PRIM_SPHERE) {
       for (int a = 0; a < 3; ++a) c0[a] = c1[a] = P.d[a];
     } else {  // the centre is linear in time (base.clj:298-302): bound its two extreme positions
       double k0 = ((double)time_lo - P.d[6]) / (P.d[7] - P.d[6]);
@@ -38,8 +39,8 @@ __device__ __forceinline__ void prim_box(const DPrim& P, float time_lo, float ti
     }
   } else {
     int ia, ib, ic;
-    if (P.type == RT_PRIM_XY_RECT) { ia = 0; ib = 1; ic = 2; }
-    else if (P.type == RT_PRIM_XZ_RECT) { ia = 0; ib = 2; ic = 1; }
+    if (type == RT_PRIM_XY_RECT) { ia = 0; ib = 1; ic = 2; }
+    else if (type == RT_PRIM_XZ_RECT) { ia = 0; ib = 2; ic = 1; }
     else { ia = 1; ib = 2; ic = 0; }
     b.mn[ia] = P.f[0]; b.mx[ia] = P.f[1];
     b.mn[ib] = P.f[2]; b.mx[ib] = P.f[3];

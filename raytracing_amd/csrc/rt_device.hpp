@@ -6,6 +6,11 @@
 // FP64 results cannot be reached otherwise (sphere quadratic, sphere u/v, camera ray, Perlin
 // cell fractions, checker sign). Each function cites the reference lines it implements
 // (paths relative to src/raytracing/).
+//
+// Every function is templated on a context type X = Ctx<FEAT>. FEAT is a compile-time mask of
+// the scene features a kernel instantiation supports; code for absent features is not
+// generated, which is what keeps the register count (hence waves per SIMD) of the common
+// instantiations low.
 #ifndef RT_DEVICE_HPP
 #define RT_DEVICE_HPP
 
@@ -19,6 +24,21 @@ namespace rt {
 
 #define RT_DEV __device__ __forceinline__
 
+// Scene tables are read-only for the lifetime of a launch. Reading them through the constant
+// address space lets wave-uniform accesses become scalar loads (s_load into SGPRs), so the
+// brute-force loops carry their primitive records in scalar registers, not in VGPRs.
+#define RT_CONST __attribute__((address_space(4)))
+template <class T>
+RT_DEV const T RT_CONST* cptr(const T* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (const T RT_CONST*)p;
+#pragma clang diagnostic pop
+}
+
+RT_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
+RT_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32, 1 ulp
+
 // ----------------------------------------------------------------------------- vectors
 struct V3 {
   float x, y, z;
@@ -31,7 +51,7 @@ RT_DEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 RT_DEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
 RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RT_DEV float len2(V3 a) { return dot(a, a); }
-RT_DEV V3 unit(V3 a) { return a * (1.0f / sqrtf(len2(a))); }  // base.clj:39-40 (v * 1/|v|)
+RT_DEV V3 unit(V3 a) { return a * rsq(len2(a)); }  // base.clj:39-40 (v * 1/|v|)
 
 struct D3 {
   double x, y, z;
@@ -84,12 +104,13 @@ RT_DEV void philox(const Rng& g, uint32_t blk, uint32_t bounce, uint32_t purpose
   uint32_t k0 = g.k0, k1 = g.k1;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    c0 = hi1 ^ c1 ^ k0;
-    c1 = lo1;
-    c2 = hi0 ^ c3 ^ k1;
-    c3 = lo0;
+    // one 32x32->64 multiply per word pair (v_mad_u64_u32)
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    c1 = (uint32_t)p1;
+    c2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c3 = (uint32_t)p0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
@@ -118,21 +139,27 @@ RT_DEV V3 random_unit_vector(const Rng& g, uint32_t bounce, T& tally) {  // base
 }
 
 // ------------------------------------------------------------------------ scene context
+template <uint32_t FEAT>
 struct Ctx {
+  static constexpr uint32_t feat = FEAT;
+  static constexpr bool has(uint32_t f) { return (FEAT & f) != 0; }
   DScene S;
-  const float* lds_perlin_vec;      // n_perlin * 1024 floats (LDS), or nullptr -> global tables
+  const float* lds_perlin_vec;      // n_perlin * 1024 floats (LDS)
   const uint8_t* lds_perlin_perm;   // n_perlin * 768 bytes (LDS)
-  int* lds_stack;                   // BVH stack base for this lane (stride = blockDim.x)
+  int* lds_stack;                   // BVH stack base of this lane (stride = blockDim.x)
   int stack_stride;
 };
 
 // --------------------------------------------------------------------------- primitives
 struct Best {
-  float t;     // closest so far (the reference's closest-so-far, base.clj:94-97)
-  int prim;    // device primitive index, -1 = none, <= -2 = medium (-2 - m)
-  int group;   // group of the winner; bit 30 set = a sphere won with its second candidate root
+  float t;   // closest so far (the reference's closest-so-far, base.clj:94-97)
+  int prim;  // device primitive index | RT_SECOND_ROOT; -1 = none; <= -2 = medium (-2 - m)
 };
-#define RT_SECOND_ROOT (1 << 30)
+#define RT_SECOND_ROOT (1 << 30)  // a sphere won with its second candidate root
+
+RT_DEV int prim_type(int type_group) { return type_group & 15; }
+RT_DEV int prim_group(int type_group) { return type_group >> 4; }
+RT_DEV bool is_rect(int type) { return type >= RT_PRIM_XY_RECT; }
 
 // Per (ray, group) constants.
 struct RayX {
@@ -145,48 +172,47 @@ struct RayX {
 RT_DEV RayX make_rayx(V3 o, V3 d, float tm) {
   RayX r;
   r.o = o; r.d = d; r.tm = tm;
-  r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  r.inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
   r.o_lo = r.d_lo = mk(0.f, 0.f, 0.f);
   return r;
 }
 RT_DEV D3 rayx_o64(const RayX& r) { return mkd((double)r.o.x + (double)r.o_lo.x, (double)r.o.y + (double)r.o_lo.y, (double)r.o.z + (double)r.o_lo.z); }
 RT_DEV D3 rayx_d64(const RayX& r) { return mkd((double)r.d.x + (double)r.d_lo.x, (double)r.d.y + (double)r.d_lo.y, (double)r.d.z + (double)r.d_lo.z); }
 
-RT_DEV bool is_rect(int type) { return type >= RT_PRIM_XY_RECT; }
-
 // rectangles.clj:20-30 (XY), :57-67 (XZ), :94-104 (YZ): t from the constant axis, reject iff
 // t < t-min or t > t-max (so equality with the closest-so-far is accepted and a later rect
-// wins an exact tie), then the inclusive in-plane bounds.
-RT_DEV bool rect_t(const DPrim& P, const RayX& r, float tmin, float tmax, float& t_out) {
+// wins an exact tie), then the inclusive in-plane bounds. Written without branches: the six
+// comparisons keep the reference's polarity (a NaN passes them, as it does there).
+template <int TYPE>
+RT_DEV bool rect_ok(float a0, float a1, float b0, float b1, float k, const RayX& r, float tmin, float tmax, float& t) {
   float oc, ic, oa, da, ob, db;
-  if (P.type == RT_PRIM_XY_RECT) { oc = r.o.z; ic = r.inv.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
-  else if (P.type == RT_PRIM_XZ_RECT) { oc = r.o.y; ic = r.inv.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
+  if (TYPE == RT_PRIM_XY_RECT) { oc = r.o.z; ic = r.inv.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
+  else if (TYPE == RT_PRIM_XZ_RECT) { oc = r.o.y; ic = r.inv.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
   else { oc = r.o.x; ic = r.inv.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
-  float t = (P.f[4] - oc) * ic;
-  if (t < tmin || t > tmax) return false;
+  t = (k - oc) * ic;
   float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
-  if (a < P.f[0] || a > P.f[1] || b < P.f[2] || b > P.f[3]) return false;
-  t_out = t;
-  return true;
+  return !(t < tmin) & !(t > tmax) & !(a < a0) & !(a > a1) & !(b < b0) & !(b > b1);
 }
 
-RT_DEV D3 sphere_center(const DPrim& P, float tm) {
-  if (P.type == RT_PRIM_SPHERE) return mkd(P.d[0], P.d[1], P.d[2]);
+template <class PRIM>
+RT_DEV D3 sphere_center(const PRIM& P, int type, float tm) {
+  if (type == RT_PRIM_SPHERE) return mkd(P.d[0], P.d[1], P.d[2]);
   // base.clj:298-302
   double k = ((double)tm - P.d[6]) / (P.d[7] - P.d[6]);
   return mkd(P.d[0] + (P.d[3] - P.d[0]) * k, P.d[1] + (P.d[4] - P.d[1]) * k,
              P.d[2] + (P.d[5] - P.d[2]) * k);
 }
-RT_DEV double sphere_radius(const DPrim& P) { return P.type == RT_PRIM_SPHERE ? P.d[3] : P.d[8]; }
+template <class PRIM>
+RT_DEV double sphere_radius(const PRIM& P, int type) { return type == RT_PRIM_SPHERE ? P.d[3] : P.d[8]; }
 
 // base.clj:234-241,247 / :274-281,287 in FP64: both candidate roots. The second candidate is
 // (-half_b + root1) / a, as the reference computes it (it adds the first root, not
 // sqrt(discriminant)). False when the discriminant is not positive.
-template <class T>
-RT_DEV bool sphere_roots(const DPrim& P, const RayX& r, double& root1, double& root2, T& tally) {
-  if (P.type == RT_PRIM_MOVING_SPHERE) tally.template add<RT_EV_MSPHERE_CENTER>();
-  D3 c = sphere_center(P, r.tm);
-  double radius = sphere_radius(P);
+template <class PRIM, class T>
+RT_DEV bool sphere_roots(const PRIM& P, int type, const RayX& r, double& root1, double& root2, T& tally) {
+  if (type == RT_PRIM_MOVING_SPHERE) tally.template add<RT_EV_MSPHERE_CENTER>();
+  D3 c = sphere_center(P, type, r.tm);
+  double radius = sphere_radius(P, type);
   D3 o = rayx_o64(r), d = rayx_d64(r);
   D3 oc = mkd(o.x - c.x, o.y - c.y, o.z - c.z);
   double a = ddot(d, d);
@@ -203,10 +229,11 @@ RT_DEV bool sphere_roots(const DPrim& P, const RayX& r, double& root1, double& r
 
 // The range tests of base.clj:242,248: t_min < root (FP64) and (float)root < t_max (strict, so
 // the earlier of two coincident spheres keeps an exact tie).
-template <class T>
-RT_DEV bool sphere_t(const DPrim& P, const RayX& r, double tmin, float tmax, float& t_out, bool& second, T& tally) {
+template <class PRIM, class T>
+RT_DEV bool sphere_t(const PRIM& P, int type, const RayX& r, double tmin, float tmax, float& t_out, bool& second,
+                     T& tally) {
   double root1, root2;
-  if (!sphere_roots(P, r, root1, root2, tally)) return false;
+  if (!sphere_roots(P, type, r, root1, root2, tally)) return false;
   tally.template add<RT_EV_SPHERE_ROOT>();
   if (root1 > tmin && (float)root1 < tmax) { t_out = (float)root1; second = false; return true; }
   tally.template add<RT_EV_SPHERE_ROOT>();
@@ -222,78 +249,118 @@ RT_DEV bool wins_tie(int cand_type, int cand_idx, int best_type, int best_idx) {
   return !is_rect(best_type) && cand_idx < best_idx;
 }
 
-// One primitive against the running best. IN_ORDER = the caller visits primitives in scan order,
-// where the comparisons of the reference give the tie rule by themselves.
-template <bool IN_ORDER, class T>
-RT_DEV void test_prim(const DScene& S, int idx, const DPrim& P, const RayX& r, float tmin, Best& best,
-                      int group, T& tally) {
+// One primitive, visited IN scan order (the brute-force loop): the comparisons of the reference
+// give the tie rule by themselves. PRIM is read through the constant address space with a
+// wave-uniform index, so `type` is uniform and the dispatch is a scalar branch.
+template <class X, class PRIM, class T>
+RT_DEV void test_prim_in_order(int idx, const PRIM& P, const RayX& r, float tmin, Best& best, T& tally) {
+  const int type = prim_type(P.type);
+  float t = 0.f;
+  bool ok = false;
+  if (type == RT_PRIM_XY_RECT) {
+    tally.template add<RT_EV_RECT_TEST>();
+    ok = rect_ok<RT_PRIM_XY_RECT>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
+  } else if (type == RT_PRIM_XZ_RECT) {
+    tally.template add<RT_EV_RECT_TEST>();
+    ok = rect_ok<RT_PRIM_XZ_RECT>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
+  } else if (type == RT_PRIM_YZ_RECT) {
+    tally.template add<RT_EV_RECT_TEST>();
+    ok = rect_ok<RT_PRIM_YZ_RECT>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
+  } else {
+    if constexpr (X::has(F_SPHERES)) {
+      bool second = false;
+      ok = sphere_t(P, type, r, (double)tmin, best.t, t, second, tally);
+      idx |= (ok && second) ? RT_SECOND_ROOT : 0;
+    }
+  }
+  best.t = ok ? t : best.t;
+  best.prim = ok ? idx : best.prim;
+}
+
+// One primitive visited OUT of scan order (BVH leaves): explicit tie rule on the ranks.
+template <class X, class T>
+RT_DEV void test_prim_any_order(const DScene& S, int idx, const RayX& r, float tmin, Best& best, T& tally) {
+  const DPrim RT_CONST* prims = cptr(S.prims);
+  const DPrim RT_CONST& P = prims[idx];
+  const int type = prim_type(P.type);
   float t;
   bool second = false;
-  if (is_rect(P.type)) {
+  if (is_rect(type)) {
     tally.template add<RT_EV_RECT_TEST>();
-    if (!rect_t(P, r, tmin, best.t, t)) return;
-    if (!IN_ORDER && t == best.t && best.prim >= 0 &&
-        !wins_tie(P.type, idx, S.prims[best.prim].type, best.prim)) return;
+    bool ok;
+    if (type == RT_PRIM_XY_RECT) ok = rect_ok<RT_PRIM_XY_RECT>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
+    else if (type == RT_PRIM_XZ_RECT) ok = rect_ok<RT_PRIM_XZ_RECT>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
+    else ok = rect_ok<RT_PRIM_YZ_RECT>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
+    if (!ok) return;
+    if (t == best.t && best.prim >= 0) {
+      int bi = best.prim & ~RT_SECOND_ROOT;
+      if (!wins_tie(type, idx, prim_type(prims[bi].type), bi)) return;
+    }
   } else {
-    if (!sphere_t(P, r, (double)tmin, IN_ORDER ? best.t : __builtin_inff(), t, second, tally)) return;
-    if (!IN_ORDER) {
+    if constexpr (X::has(F_SPHERES)) {
+      if (!sphere_t(P, type, r, (double)tmin, __builtin_inff(), t, second, tally)) return;
       if (t > best.t) return;
       if (t == best.t) {
         if (best.prim < 0) return;  // t == t_max with nothing hit yet: the strict test fails
-        if (!wins_tie(P.type, idx, S.prims[best.prim].type, best.prim)) return;
+        int bi = best.prim & ~RT_SECOND_ROOT;
+        if (!wins_tie(type, idx, prim_type(prims[bi].type), bi)) return;
       }
+    } else {
+      return;
     }
   }
-  best.t = t; best.prim = idx; best.group = second ? (group | RT_SECOND_ROOT) : group;
+  best.t = t;
+  best.prim = second ? (idx | RT_SECOND_ROOT) : idx;
 }
 
 // ------------------------------------------------------------------------------- chains
-template <class T>
-RT_DEV void chain_apply(const DScene& S, int chain, V3& o, V3& d, T& tally) {
-  const DChain C = S.chains[chain];
-  for (int i = 0; i < C.n_ops; ++i) {
-    const DChainOp op = S.ops[C.first_op + i];
-    if (op.kind == DOP_TRANSLATE) {  // translate.clj:11
-      o = mk(o.x - op.a, o.y - op.b, o.z - op.c);
-      tally.template add<RT_EV_TRANSLATE_RAY>();
-    } else {  // rotate.clj:18-27
-      // explicit FMAs: every inlined copy must round identically
-      float s = op.a, c = op.b;
-      o = mk(fmaf(c, o.x, -(s * o.z)), o.y, fmaf(s, o.x, c * o.z));
-      d = mk(fmaf(c, d.x, -(s * d.z)), d.y, fmaf(s, d.x, c * d.z));
-      tally.template add<RT_EV_ROTATE_RAY>();
+// The ray of a group: its chain applied to the world ray (translate.clj:11, rotate.clj:18-27).
+// Groups with spheres below a chain get the transform in FP64 on the exact FP32 world ray,
+// split into an FP32 value and an FP32 residual, so the FP64 sphere test sees what the
+// reference sees. Chain records are wave-uniform: their operands live in SGPRs.
+template <class X, class T>
+RT_DEV RayX group_ray(const DScene& S, int chain, int group_flags, const Ray& wr, T& tally) {
+  if constexpr (!X::has(F_CHAINS)) {
+    return make_rayx(wr.o, wr.d, wr.tm);
+  } else {
+    const DChain RT_CONST* chains = cptr(S.chains);
+    const DChainOp RT_CONST* ops = cptr(S.ops);
+    const int first_op = chains[chain].first_op, n_ops = chains[chain].n_ops;
+    if (!X::has(F_SPHERES) || !(group_flags & DGROUP_SPHERES_UNDER_CHAIN)) {
+      V3 o = wr.o, d = wr.d;
+      for (int i = 0; i < n_ops; ++i) {
+        const DChainOp RT_CONST& op = ops[first_op + i];
+        if (op.kind == DOP_TRANSLATE) {
+          o = mk(o.x - op.a, o.y - op.b, o.z - op.c);
+          tally.template add<RT_EV_TRANSLATE_RAY>();
+        } else {
+          // explicit FMAs: every inlined copy must round identically
+          float s = op.a, c = op.b;
+          o = mk(fmaf(c, o.x, -(s * o.z)), o.y, fmaf(s, o.x, c * o.z));
+          d = mk(fmaf(c, d.x, -(s * d.z)), d.y, fmaf(s, d.x, c * d.z));
+          tally.template add<RT_EV_ROTATE_RAY>();
+        }
+      }
+      return make_rayx(o, d, wr.tm);
     }
-  }
-}
-
-// The ray of group g: its chain applied to the world ray. Groups with spheres below a chain get
-// the transform in FP64 (translate.clj:11, rotate.clj:18-27 on the exact FP32 world ray), split
-// into an FP32 value and an FP32 residual, so the FP64 sphere test sees what the reference sees.
-template <class T>
-RT_DEV RayX group_ray(const DScene& S, const DGroup& G, const Ray& wr, T& tally) {
-  if (!(G.flags & DGROUP_SPHERES_UNDER_CHAIN)) {
-    V3 o = wr.o, d = wr.d;
-    chain_apply(S, G.chain, o, d, tally);
-    return make_rayx(o, d, wr.tm);
-  }
-  D3 o = tod(wr.o), d = tod(wr.d);
-  const DChain C = S.chains[G.chain];
-  for (int i = 0; i < C.n_ops; ++i) {
-    const DChainOp op = S.ops[C.first_op + i];
-    if (op.kind == DOP_TRANSLATE) {
-      o = mkd(o.x - op.da, o.y - op.db, o.z - op.dc);
-      tally.template add<RT_EV_TRANSLATE_RAY>();
-    } else {
-      double s = op.da, c = op.db;
-      o = mkd(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
-      d = mkd(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
-      tally.template add<RT_EV_ROTATE_RAY>();
+    D3 o = tod(wr.o), d = tod(wr.d);
+    for (int i = 0; i < n_ops; ++i) {
+      const DChainOp RT_CONST& op = ops[first_op + i];
+      if (op.kind == DOP_TRANSLATE) {
+        o = mkd(o.x - op.da, o.y - op.db, o.z - op.dc);
+        tally.template add<RT_EV_TRANSLATE_RAY>();
+      } else {
+        double s = op.da, c = op.db;
+        o = mkd(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
+        d = mkd(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
+        tally.template add<RT_EV_ROTATE_RAY>();
+      }
     }
+    RayX r = make_rayx(tof(o), tof(d), wr.tm);
+    r.o_lo = mk((float)(o.x - (double)r.o.x), (float)(o.y - (double)r.o.y), (float)(o.z - (double)r.o.z));
+    r.d_lo = mk((float)(d.x - (double)r.d.x), (float)(d.y - (double)r.d.y), (float)(d.z - (double)r.d.z));
+    return r;
   }
-  RayX r = make_rayx(tof(o), tof(d), wr.tm);
-  r.o_lo = mk((float)(o.x - (double)r.o.x), (float)(o.y - (double)r.o.y), (float)(o.z - (double)r.o.z));
-  r.d_lo = mk((float)(d.x - (double)r.d.x), (float)(d.y - (double)r.d.y), (float)(d.z - (double)r.d.z));
-  return r;
 }
 
 // ---------------------------------------------------------------------------------- BVH
@@ -308,17 +375,18 @@ RT_DEV bool slab(const float* mn, const float* mx, const RayX& r, float tmin, fl
   return tn <= tf;
 }
 
-template <class T>
-RT_DEV void bvh_traverse(const Ctx& X, int root, const RayX& r, float tmin, Best& best, int group, T& tally) {
-  const DScene& S = X.S;
+template <class X, class T>
+RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best& best, T& tally) {
+  const DScene& S = ctx.S;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 RT_CONST* nodes4 = reinterpret_cast<const f4 RT_CONST*>(cptr(S.nodes));
   int sp = 0;
   int node = root;
   for (;;) {
-    const DBvhNode* N = &S.nodes[node];
-    const float4 q0 = reinterpret_cast<const float4*>(N)[0];
-    const float4 q1 = reinterpret_cast<const float4*>(N)[1];
-    const float4 q2 = reinterpret_cast<const float4*>(N)[2];
-    const float4 q3 = reinterpret_cast<const float4*>(N)[3];
+    const f4 q0 = nodes4[node * 4 + 0];
+    const f4 q1 = nodes4[node * 4 + 1];
+    const f4 q2 = nodes4[node * 4 + 2];
+    const f4 q3 = nodes4[node * 4 + 3];
     const float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
     const float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
     int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
@@ -327,9 +395,9 @@ RT_DEV void bvh_traverse(const Ctx& X, int root, const RayX& r, float tmin, Best
     bool hl = slab(lmin, lmax, r, tmin, best.t, tl);
     bool hr = slab(rmin, rmax, r, tmin, best.t, tr);
     // leaves are tested on the spot; internal children are visited near child first
-    if (hl && left < 0) { test_prim<false>(S, ~left, S.prims[~left], r, tmin, best, group, tally); hl = false; }
+    if (hl && left < 0) { test_prim_any_order<X>(S, ~left, r, tmin, best, tally); hl = false; }
     if (hr && right < 0) {
-      if (tr <= best.t) test_prim<false>(S, ~right, S.prims[~right], r, tmin, best, group, tally);
+      if (tr <= best.t) test_prim_any_order<X>(S, ~right, r, tmin, best, tally);
       hr = false;
     }
     if (hl && tl > best.t) hl = false;
@@ -337,7 +405,7 @@ RT_DEV void bvh_traverse(const Ctx& X, int root, const RayX& r, float tmin, Best
     if (hl && hr) {
       int near = left, far = right;
       if (tr < tl) { near = right; far = left; }
-      X.lds_stack[sp * X.stack_stride] = far;
+      ctx.lds_stack[sp * ctx.stack_stride] = far;
       ++sp;
       node = near;
     } else if (hl) {
@@ -347,23 +415,24 @@ RT_DEV void bvh_traverse(const Ctx& X, int root, const RayX& r, float tmin, Best
     } else {
       if (sp == 0) break;
       --sp;
-      node = X.lds_stack[sp * X.stack_stride];
+      node = ctx.lds_stack[sp * ctx.stack_stride];
     }
   }
 }
 
-// Closest hit of one group (its chain already applied to r) with t in (tmin, best.t].
-template <class T>
-RT_DEV void group_hit(const Ctx& X, int g, const RayX& r, float tmin, Best& best, T& tally) {
-  const DScene& S = X.S;
-  const DGroup G = S.groups[g];
-  if (G.bvh_root >= 0) {
-    bvh_traverse(X, G.bvh_root, r, tmin, best, g, tally);
+// Closest hit of group g for the world ray wr with t in (tmin, best.t].
+template <class X, class T>
+RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best, T& tally) {
+  const DScene& S = ctx.S;
+  const DGroup RT_CONST& G = cptr(S.groups)[g];
+  const RayX r = group_ray<X>(S, G.chain, G.flags, wr, tally);
+  const int bvh_root = G.bvh_root;
+  if (X::has(F_BVH) && bvh_root >= 0) {
+    if constexpr (X::has(F_BVH)) bvh_traverse(ctx, bvh_root, r, tmin, best, tally);
   } else {
-    for (int i = 0; i < G.n_prims; ++i) {
-      int idx = G.first_prim + i;
-      test_prim<true>(S, idx, S.prims[idx], r, tmin, best, g, tally);
-    }
+    const DPrim RT_CONST* prims = cptr(S.prims);
+    const int first = G.first_prim, n = G.n_prims;
+    for (int i = 0; i < n; ++i) test_prim_in_order<X>(first + i, prims[first + i], r, tmin, best, tally);
   }
 }
 
@@ -385,109 +454,116 @@ RT_DEV void sphere_uv(D3 n, float& u, float& v) {
 }
 
 // The HitRecord of primitive `prim` for the (chain-space) ray r at parameter t.
-template <class T>
+template <class X, class T>
 RT_DEV void prim_record(const DScene& S, int prim, const RayX& r, float t, bool second_root, bool want_uv,
                         Rec& rec, T& tally) {
-  const DPrim& P = S.prims[prim];
+  const DPrim RT_CONST& P = cptr(S.prims)[prim];
+  const int type = prim_type(P.type);
   rec.mat = P.mat;
   rec.t = t;
   rec.u = rec.v = 0.f;
-  if (is_rect(P.type)) {
+  if (!X::has(F_SPHERES) || is_rect(type)) {
     // rectangles.clj:31-37; the in-plane point is o + t d, the constant coordinate is set to k
     // (in FP64 the reference's o + t d lands on k to 1e-13; FP32 rounding would not).
     tally.template add<RT_EV_RECT_RECORD>();
+    const float k = P.f[4];
     V3 p = mk(fmaf(t, r.d.x, r.o.x), fmaf(t, r.d.y, r.o.y), fmaf(t, r.d.z, r.o.z));
     float a, b, dn;
     V3 out;
-    if (P.type == RT_PRIM_XY_RECT) { p.z = P.f[4]; a = p.x; b = p.y; dn = r.d.z; out = mk(0, 0, 1); }
-    else if (P.type == RT_PRIM_XZ_RECT) { p.y = P.f[4]; a = p.x; b = p.z; dn = r.d.y; out = mk(0, 1, 0); }
-    else { p.x = P.f[4]; a = p.y; b = p.z; dn = r.d.x; out = mk(1, 0, 0); }
-    rec.u = (a - P.f[0]) / (P.f[1] - P.f[0]);
-    rec.v = (b - P.f[2]) / (P.f[3] - P.f[2]);
+    if (type == RT_PRIM_XY_RECT) { p.z = k; a = p.x; b = p.y; dn = r.d.z; out = mk(0, 0, 1); }
+    else if (type == RT_PRIM_XZ_RECT) { p.y = k; a = p.x; b = p.z; dn = r.d.y; out = mk(0, 1, 0); }
+    else { p.x = k; a = p.y; b = p.z; dn = r.d.x; out = mk(1, 0, 0); }
+    if (want_uv) {
+      rec.u = (a - P.f[0]) / (P.f[1] - P.f[0]);
+      rec.v = (b - P.f[2]) / (P.f[3] - P.f[2]);
+    }
     rec.front = dn < 0.0f;  // set-face-normal, base.clj:171-174
     rec.n = rec.front ? out : neg(out);
     rec.p = p;
   } else {
-    // base.clj:243-246 in FP64 from the FP64 root (recomputed: only the winner pays for it)
-    tally.template add<RT_EV_SPHERE_RECORD>();
-    Tally<false> quiet;
-    double root1 = (double)t, root2 = (double)t;
-    sphere_roots(P, r, root1, root2, quiet);
-    double root = second_root ? root2 : root1;
-    D3 c = sphere_center(P, r.tm);
-    double inv_r = 1.0 / sphere_radius(P);
-    D3 o64 = rayx_o64(r), d64 = rayx_d64(r);
-    D3 pd = mkd(o64.x + root * d64.x, o64.y + root * d64.y, o64.z + root * d64.z);
-    D3 out = mkd((pd.x - c.x) * inv_r, (pd.y - c.y) * inv_r, (pd.z - c.z) * inv_r);
-    if (want_uv) sphere_uv(out, rec.u, rec.v);
-    rec.front = ddot(d64, out) < 0.0;
-    rec.n = rec.front ? tof(out) : neg(tof(out));
-    rec.p = tof(pd);
+    if constexpr (X::has(F_SPHERES)) {
+      // base.clj:243-246 in FP64 from the FP64 root (recomputed: only the winner pays for it)
+      tally.template add<RT_EV_SPHERE_RECORD>();
+      Tally<false> quiet;
+      double root1 = (double)t, root2 = (double)t;
+      sphere_roots(P, type, r, root1, root2, quiet);
+      double root = second_root ? root2 : root1;
+      D3 c = sphere_center(P, type, r.tm);
+      double inv_r = 1.0 / sphere_radius(P, type);
+      D3 o64 = rayx_o64(r), d64 = rayx_d64(r);
+      D3 pd = mkd(o64.x + root * d64.x, o64.y + root * d64.y, o64.z + root * d64.z);
+      D3 out = mkd((pd.x - c.x) * inv_r, (pd.y - c.y) * inv_r, (pd.z - c.z) * inv_r);
+      if (want_uv) sphere_uv(out, rec.u, rec.v);
+      rec.front = ddot(d64, out) < 0.0;
+      rec.n = rec.front ? tof(out) : neg(tof(out));
+      rec.p = tof(pd);
+    }
   }
 }
 
 // Record fix-ups on the way back up a chain: rotate.clj:31-47 (both components use +sin, and the
 // face test is against the ROTATED ray) then translate.clj:13-17 (face test against the moved
 // ray, whose direction is the outer one).
-template <class T>
+template <class X, class T>
 RT_DEV void chain_unwind(const DScene& S, int chain, V3 world_d, Rec& rec, T& tally) {
-  const DChain C = S.chains[chain];
-  if (C.n_ops == 0) return;
-  V3 dirs[RT_MAX_CHAIN_OPS + 1];
-  dirs[0] = world_d;
+  if constexpr (X::has(F_CHAINS)) {
+    const DChain RT_CONST* chains = cptr(S.chains);
+    const DChainOp RT_CONST* ops = cptr(S.ops);
+    const int first_op = chains[chain].first_op, n_ops = chains[chain].n_ops;
+    if (n_ops == 0) return;
+    V3 dirs[RT_MAX_CHAIN_OPS + 1];
+    dirs[0] = world_d;
 #pragma unroll
-  for (int i = 0; i < RT_MAX_CHAIN_OPS; ++i) {
-    V3 d = dirs[i];
-    if (i < C.n_ops) {
-      const DChainOp op = S.ops[C.first_op + i];
-      if (op.kind == DOP_ROTATE_Y) d = mk(op.b * d.x - op.a * d.z, d.y, op.a * d.x + op.b * d.z);
+    for (int i = 0; i < RT_MAX_CHAIN_OPS; ++i) {
+      V3 d = dirs[i];
+      if (i < n_ops) {
+        const DChainOp RT_CONST& op = ops[first_op + i];
+        if (op.kind == DOP_ROTATE_Y) d = mk(fmaf(op.b, d.x, -(op.a * d.z)), d.y, fmaf(op.a, d.x, op.b * d.z));
+      }
+      dirs[i + 1] = d;
     }
-    dirs[i + 1] = d;
-  }
 #pragma unroll
-  for (int i = RT_MAX_CHAIN_OPS - 1; i >= 0; --i) {
-    if (i < C.n_ops) {
-      const DChainOp op = S.ops[C.first_op + i];
-      V3 d_inner = dirs[i + 1];
-      if (op.kind == DOP_ROTATE_Y) {
-        float s = op.a, c = op.b;
-        V3 p = rec.p, n = rec.n;
-        rec.p = mk(c * p.x + s * p.z, p.y, s * p.x + c * p.z);
-        V3 nn = mk(c * n.x + s * n.z, n.y, s * n.x + c * n.z);
-        rec.front = dot(d_inner, nn) < 0.0f;
-        rec.n = rec.front ? nn : neg(nn);
-        tally.template add<RT_EV_ROTATE_REC>();
-      } else {
-        rec.front = dot(d_inner, rec.n) < 0.0f;
-        rec.n = rec.front ? rec.n : neg(rec.n);
-        rec.p = mk(rec.p.x + op.a, rec.p.y + op.b, rec.p.z + op.c);
-        tally.template add<RT_EV_TRANSLATE_REC>();
+    for (int i = RT_MAX_CHAIN_OPS - 1; i >= 0; --i) {
+      if (i < n_ops) {
+        const DChainOp RT_CONST& op = ops[first_op + i];
+        V3 d_inner = dirs[i + 1];
+        if (op.kind == DOP_ROTATE_Y) {
+          float s = op.a, c = op.b;
+          V3 p = rec.p, n = rec.n;
+          rec.p = mk(c * p.x + s * p.z, p.y, s * p.x + c * p.z);
+          V3 nn = mk(c * n.x + s * n.z, n.y, s * n.x + c * n.z);
+          rec.front = dot(d_inner, nn) < 0.0f;
+          rec.n = rec.front ? nn : neg(nn);
+          tally.template add<RT_EV_ROTATE_REC>();
+        } else {
+          rec.front = dot(d_inner, rec.n) < 0.0f;
+          rec.n = rec.front ? rec.n : neg(rec.n);
+          rec.p = mk(rec.p.x + op.a, rec.p.y + op.b, rec.p.z + op.c);
+          tally.template add<RT_EV_TRANSLATE_REC>();
+        }
       }
     }
   }
 }
 
 // -------------------------------------------------------------------------------- media
-// constant_medium.clj:11-38 for medium m; xi is the uniform of line 32. Returns the hit
-// parameter or a negative value for "no hit"; t in [t1, t2] within (tmin, tmax].
-template <class T>
-RT_DEV bool medium_t(const Ctx& X, int m, const Ray& wr, float tmin, float tmax, float xi, bool have_xi,
+// constant_medium.clj:11-38 for medium m; xi is the uniform of line 32 (scripted when have_xi,
+// else drawn from the keyed stream). True with the hit parameter when the free-flight distance
+// ends inside the boundary, t in [t1, t2] within (tmin, tmax]. The boundary groups carry their
+// full chains, so they take the world ray; ray length and t do not depend on the chain.
+template <class X, class T>
+RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax, float xi, bool have_xi,
                      const Rng& g, uint32_t bounce, float& t_out, T& tally) {
-  const DScene& S = X.S;
-  const DMedium M = S.media[m];
+  const DScene& S = ctx.S;
+  const DMedium RT_CONST& M = cptr(S.media)[m];
   const float INF = __builtin_inff();
+  const int first_group = M.first_group, n_groups = M.n_groups;
   // rec1 = hit boundary (-inf, +inf); rec2 = hit boundary (rec1.t + 0.0001, +inf)
-  Best b1{INF, -1, -1};
-  for (int gi = 0; gi < M.n_groups; ++gi) {
-    int gidx = M.first_group + gi;
-    group_hit(X, gidx, group_ray(S, S.groups[gidx], wr, tally), -INF, b1, tally);
-  }
+  Best b1{INF, -1};
+  for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, -INF, b1, tally);
   if (b1.prim < 0) return false;
-  Best b2{INF, -1, -1};
-  for (int gi = 0; gi < M.n_groups; ++gi) {
-    int gidx = M.first_group + gi;
-    group_hit(X, gidx, group_ray(S, S.groups[gidx], wr, tally), b1.t + 0.0001f, b2, tally);
-  }
+  Best b2{INF, -1};
+  for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, b1.t + 0.0001f, b2, tally);
   if (b2.prim < 0) return false;
   float t1 = (b1.t < tmin) ? tmin : b1.t;
   float t2 = (b2.t > tmax) ? tmax : b2.t;
@@ -512,47 +588,52 @@ RT_DEV bool medium_t(const Ctx& X, int m, const Ray& wr, float tmin, float tmax,
 // (hit (->HittableList world) r t-min t-max {}) of core.clj:23 over the flattened world.
 // medium_xi: scripted uniforms per medium (parity hook) or nullptr to draw from `g`;
 // skip_media drops MEDIUM nodes altogether.
-template <class T>
-RT_DEV bool closest_hit(const Ctx& X, const Ray& wr, float tmin, float tmax, const Rng& g, uint32_t bounce,
+template <class X, class T>
+RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, const Rng& g, uint32_t bounce,
                         const float* medium_xi, bool skip_media, bool want_uv_always, Rec& rec, T& tally) {
-  const DScene& S = X.S;
-  Best best{tmax, -1, -1};
-  for (int gi = 0; gi < S.n_surface_groups; ++gi)
-    group_hit(X, gi, group_ray(S, S.groups[gi], wr, tally), tmin, best, tally);
-  if (!skip_media) {
-    for (int m = 0; m < S.n_media; ++m) {
-      // the medium lives under its own outer chain; lengths and t are chain-invariant
-      V3 o = wr.o, d = wr.d;
-      chain_apply(S, S.media[m].outer_chain, o, d, tally);
-      Ray mr{o, d, wr.tm};
-      float tm;
-      if (medium_t(X, m, mr, tmin, best.t, medium_xi ? medium_xi[m] : 0.f, medium_xi != nullptr, g, bounce,
-                   tm, tally)) {
-        best.t = tm; best.prim = -2 - m; best.group = -1;
+  const DScene& S = ctx.S;
+  Best best{tmax, -1};
+  const int n_surface = S.n_surface_groups;
+  for (int gi = 0; gi < n_surface; ++gi) group_hit(ctx, gi, wr, tmin, best, tally);
+  if constexpr (X::has(F_MEDIA)) {
+    if (!skip_media) {
+      const int n_media = S.n_media;
+      for (int m = 0; m < n_media; ++m) {
+        float tm;
+        if (medium_t(ctx, m, wr, tmin, best.t, medium_xi ? medium_xi[m] : 0.f, medium_xi != nullptr, g, bounce,
+                     tm, tally)) {
+          best.t = tm; best.prim = -2 - m;
+        }
       }
     }
   }
   if (best.prim == -1) return false;
-  if (best.prim >= 0) {
-    const bool second_root = (best.group & RT_SECOND_ROOT) != 0;
-    best.group &= ~RT_SECOND_ROOT;
-    int chain = S.groups[best.group].chain;
-    RayX rx = group_ray(S, S.groups[best.group], wr, tally);
-    bool want_uv = want_uv_always || S.mats[S.prims[best.prim].mat].needs_uv != 0;
-    prim_record(S, best.prim, rx, best.t, second_root, want_uv, rec, tally);
-    chain_unwind(S, chain, wr.d, rec, tally);
+  if (!X::has(F_MEDIA) || best.prim >= 0) {
+    const bool second_root = (best.prim & RT_SECOND_ROOT) != 0;
+    const int prim = best.prim & ~RT_SECOND_ROOT;
+    const int group = prim_group(cptr(S.prims)[prim].type);
+    const DGroup RT_CONST& G = cptr(S.groups)[group];
+    const int chain = G.chain;
+    RayX rx = group_ray<X>(S, chain, G.flags, wr, tally);
+    bool want_uv = want_uv_always;
+    if constexpr (X::has(F_TEXTURES))
+      want_uv = want_uv || (cptr(S.mats)[cptr(S.prims)[prim].mat].flags & DMAT_NEEDS_UV) != 0;
+    prim_record<X>(S, prim, rx, best.t, second_root, want_uv, rec, tally);
+    chain_unwind<X>(S, chain, wr.d, rec, tally);
   } else {
-    // constant_medium.clj:38-44: p = ray-at r t, normal [1 0 0], front-face true, no u/v
-    const DMedium M = S.media[-2 - best.prim];
-    V3 o = wr.o, d = wr.d;
-    chain_apply(S, M.outer_chain, o, d, tally);
-    rec.t = best.t;
-    rec.p = mk(fmaf(best.t, d.x, o.x), fmaf(best.t, d.y, o.y), fmaf(best.t, d.z, o.z));
-    rec.n = mk(1.f, 0.f, 0.f);
-    rec.front = true;
-    rec.mat = M.phase_mat;
-    rec.u = rec.v = 0.f;
-    chain_unwind(S, M.outer_chain, wr.d, rec, tally);
+    if constexpr (X::has(F_MEDIA)) {
+      // constant_medium.clj:38-44: p = ray-at r t, normal [1 0 0], front-face true, no u/v
+      const DMedium RT_CONST& M = cptr(S.media)[-2 - best.prim];
+      const int outer = M.outer_chain;
+      RayX mr = group_ray<X>(S, outer, 0, wr, tally);
+      rec.t = best.t;
+      rec.p = mk(fmaf(best.t, mr.d.x, mr.o.x), fmaf(best.t, mr.d.y, mr.o.y), fmaf(best.t, mr.d.z, mr.o.z));
+      rec.n = mk(1.f, 0.f, 0.f);
+      rec.front = true;
+      rec.mat = M.phase_mat;
+      rec.u = rec.v = 0.f;
+      chain_unwind<X>(S, outer, wr.d, rec, tally);
+    }
   }
   return true;
 }
@@ -562,22 +643,15 @@ RT_DEV float hermite(float x) { return x * x * (3.0f - 2.0f * x); }
 
 // noise.clj:39-58 + :21-33. The cell index and fraction come from FP64 (p * 2^k is exact there),
 // the rest is FP32. Both Hermite passes and the OR of the three permutation entries are the
-// reference's.
-template <class T>
-RT_DEV float perlin_noise(const Ctx& X, int pid, D3 p, T& tally) {
+// reference's. Tables are read from LDS.
+template <class X, class T>
+RT_DEV float perlin_noise(const X& ctx, int pid, D3 p, T& tally) {
   tally.template add<RT_EV_PERLIN_NOISE>();
   double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
   float u = hermite((float)(p.x - fx)), v = hermite((float)(p.y - fy)), w = hermite((float)(p.z - fz));
   int i = (int)(long long)fx, j = (int)(long long)fy, k = (int)(long long)fz;
-  const uint8_t* perm;
-  const float4* vec;
-  if (X.lds_perlin_vec) {
-    perm = X.lds_perlin_perm + pid * 768;
-    vec = reinterpret_cast<const float4*>(X.lds_perlin_vec) + pid * 256;
-  } else {
-    perm = X.S.perlin_perm + pid * 768;
-    vec = reinterpret_cast<const float4*>(X.S.perlin_vec) + pid * 256;
-  }
+  const uint8_t* perm = ctx.lds_perlin_perm + pid * 768;
+  const float4* vec = reinterpret_cast<const float4*>(ctx.lds_perlin_vec) + pid * 256;
   float uu = hermite(u), vv = hermite(v), ww = hermite(w);
   float acc = 0.f;
 #pragma unroll
@@ -602,12 +676,12 @@ RT_DEV float perlin_noise(const Ctx& X, int pid, D3 p, T& tally) {
 }
 
 // noise.clj:59-70
-template <class T>
-RT_DEV float perlin_turb(const Ctx& X, int pid, V3 p, int depth, T& tally) {
+template <class X, class T>
+RT_DEV float perlin_turb(const X& ctx, int pid, V3 p, int depth, T& tally) {
   float acc = 0.f, weight = 1.f;
   D3 tp = tod(p);
   for (int i = 0; i < depth; ++i) {
-    acc += weight * perlin_noise(X, pid, tp, tally);
+    acc += weight * perlin_noise(ctx, pid, tp, tally);
     weight *= 0.5f;
     tp = mkd(tp.x * 2.0, tp.y * 2.0, tp.z * 2.0);
   }
@@ -621,42 +695,55 @@ RT_DEV bool sin_negative(double x) {
 }
 
 // texture.clj: value of texture `tex` at (u, v, p).
-template <class T>
-RT_DEV V3 texture_value(const Ctx& X, int tex, float u, float v, V3 p, T& tally) {
-  const DScene& S = X.S;
-  DTex t = S.texs[tex];
-  for (int depth = 0; t.type == RT_TEX_CHECKER && depth < 16; ++depth) {  // :25-30
+template <class X, class T>
+RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, T& tally) {
+  const DScene& S = ctx.S;
+  const DTex RT_CONST* texs = cptr(S.texs);
+  int type = texs[tex].type;
+  for (int depth = 0; type == RT_TEX_CHECKER && depth < 16; ++depth) {  // :25-30
     tally.template add<RT_EV_CHECKER>();
     bool nx = sin_negative(10.0 * (double)p.x), ny = sin_negative(10.0 * (double)p.y),
          nz = sin_negative(10.0 * (double)p.z);
     // the product of the three sines is negative iff an odd number of them is, and is +-0 (not
     // negative) when a coordinate is exactly 0
     bool negative = ((nx != ny) != nz) && p.x != 0.0f && p.y != 0.0f && p.z != 0.0f;
-    t = S.texs[negative ? t.i0 : t.i1];
+    tex = negative ? texs[tex].i0 : texs[tex].i1;
+    type = texs[tex].type;
   }
-  if (t.type == RT_TEX_SOLID) return mk(t.r, t.g, t.b);  // :15-17
-  if (t.type == RT_TEX_NOISE) {                          // :41-44
+  if (type == RT_TEX_SOLID) return mk(texs[tex].r, texs[tex].g, texs[tex].b);  // :15-17
+  if (type == RT_TEX_NOISE) {                                                  // :41-44
     tally.template add<RT_EV_NOISE_TEX>();
-    float k = 0.5f * (1.0f + sinf((float)t.i1 * p.z + 10.0f * perlin_turb(X, t.i0, p, 7, tally)));
+    float k = 0.5f * (1.0f + sinf((float)texs[tex].i1 * p.z + 10.0f * perlin_turb(ctx, texs[tex].i0, p, 7, tally)));
     return mk(k, k, k);
   }
-  if (t.type == RT_TEX_IMAGE) {  // :55-66
+  if (type == RT_TEX_IMAGE) {  // :55-66
     tally.template add<RT_EV_IMAGE_TEX>();
-    if (t.i0 < 0) return mk(0.f, 1.f, 1.f);
-    const DImage im = S.images[t.i0];
+    const int img = texs[tex].i0;
+    if (img < 0) return mk(0.f, 1.f, 1.f);
+    const DImage RT_CONST& im = cptr(S.images)[img];
+    const int w = im.w, h = im.h;
     float uu = (0.0f > u) ? 0.0f : (u > 1.0f ? 1.0f : u);   // clamp, base.clj:307-310 (NaN stays)
     float vc = (0.0f > v) ? 0.0f : (v > 1.0f ? 1.0f : v);
     float vv = 1.0f - vc;
-    float fi = uu * (float)im.w, fj = vv * (float)im.h;
+    float fi = uu * (float)w, fj = vv * (float)h;
     int i = (fi != fi) ? 0 : (int)fi;  // (int NaN) = 0 on the JVM
     int j = (fj != fj) ? 0 : (int)fj;
-    if (i >= im.w) i = im.w - 1;
-    if (j >= im.h) j = im.h - 1;
-    uint32_t px = S.texels[im.first_texel + j * im.w + i];
+    if (i >= w) i = w - 1;
+    if (j >= h) j = h - 1;
+    uint32_t px = cptr(S.texels)[im.first_texel + j * w + i];
     const float cs = 1.0f / 255.0f;
     return mk((float)(px & 255u) * cs, (float)((px >> 8) & 255u) * cs, (float)((px >> 16) & 255u) * cs);
   }
   return mk(0.f, 0.f, 0.f);
+}
+
+// The colour of a textured material: solid colours are folded into the material record.
+template <class X, class T>
+RT_DEV V3 material_colour(const X& ctx, int flags, int tex, V3 solid, const Rec& rec, T& tally) {
+  if constexpr (X::has(F_TEXTURES)) {
+    if (!(flags & DMAT_SOLID)) return texture_value(ctx, tex, rec.u, rec.v, rec.p, tally);
+  }
+  return solid;
 }
 
 // ------------------------------------------------------------------------------ materials
@@ -677,28 +764,36 @@ RT_DEV float reflectance(float cosine, float ref_idx) {  // base.clj:215-220
 
 // (scatter mat r rec) and (emitted mat u v p) of materials.clj. Returns ok; on ok the ray is
 // replaced by the scattered ray. `emitted` is only meaningful when !ok (core.clj:26-29).
-template <class T>
-RT_DEV bool scatter(const Ctx& X, const Rec& rec, Ray& r, const Rng& g, uint32_t bounce, V3& attenuation,
+template <class X, class T>
+RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t bounce, V3& attenuation,
                     V3& emitted, T& tally) {
-  const DMat M = X.S.mats[rec.mat];
+  const DMat RT_CONST& M = cptr(ctx.S.mats)[rec.mat];
+  const int type = M.type, flags = M.flags, tex = M.tex;
+  const V3 rgb = mk(M.r, M.g, M.b);
   emitted = mk(0.f, 0.f, 0.f);
-  switch (M.type) {
-    case RT_MAT_LAMBERTIAN: {  // :16-23
-      tally.template add<RT_EV_LAMBERT>();
-      V3 dir = rec.n + random_unit_vector(g, bounce, tally);
-      attenuation = texture_value(X, M.tex, rec.u, rec.v, rec.p, tally);
-      r.o = rec.p; r.d = dir;
-      return true;
-    }
-    case RT_MAT_METAL: {  // :33-39
+  if (type == RT_MAT_LAMBERTIAN) {  // :16-23
+    tally.template add<RT_EV_LAMBERT>();
+    V3 dir = rec.n + random_unit_vector(g, bounce, tally);
+    attenuation = material_colour(ctx, flags, tex, rgb, rec, tally);
+    r.o = rec.p; r.d = dir;
+    return true;
+  }
+  if (type == RT_MAT_DIFFUSE_LIGHT) {  // :69-78 (the unused scatter direction is not drawn)
+    tally.template add<RT_EV_LIGHT>();
+    emitted = material_colour(ctx, flags, tex, rgb, rec, tally);
+    attenuation = emitted;
+    return false;
+  }
+  if constexpr (X::has(F_SPECULAR)) {
+    if (type == RT_MAT_METAL) {  // :33-39
       tally.template add<RT_EV_METAL>();
       V3 reflected = reflect(unit(r.d), rec.n);
       V3 dir = reflected + random_in_unit_sphere(g, bounce, tally) * M.x;
-      attenuation = mk(M.r, M.g, M.b);
+      attenuation = rgb;
       r.o = rec.p; r.d = dir;
       return dot(dir, rec.n) > 0.0f;
     }
-    case RT_MAT_DIELECTRIC: {  // :47-61
+    if (type == RT_MAT_DIELECTRIC) {  // :47-61
       tally.template add<RT_EV_DIELECTRIC>();
       float ir = M.r;
       float ratio = rec.front ? (1.0f / ir) : ir;
@@ -716,20 +811,18 @@ RT_DEV bool scatter(const Ctx& X, const Rec& rec, Ray& r, const Rng& g, uint32_t
       r.o = rec.p; r.d = dir;
       return true;
     }
-    case RT_MAT_DIFFUSE_LIGHT: {  // :69-78 (the unused scatter direction is not drawn)
-      tally.template add<RT_EV_LIGHT>();
-      emitted = texture_value(X, M.tex, rec.u, rec.v, rec.p, tally);
-      attenuation = emitted;
-      return false;
-    }
-    default: {  // RT_MAT_ISOTROPIC :87-90 — direction not normalised
+  }
+  if constexpr (X::has(F_MEDIA)) {
+    if (type == RT_MAT_ISOTROPIC) {  // :87-90 — direction not normalised
       tally.template add<RT_EV_ISOTROPIC>();
       V3 dir = random_in_unit_sphere(g, bounce, tally);
-      attenuation = texture_value(X, M.tex, rec.u, rec.v, rec.p, tally);
+      attenuation = material_colour(ctx, flags, tex, rgb, rec, tally);
       r.o = rec.p; r.d = dir;
       return true;
     }
   }
+  attenuation = mk(0.f, 0.f, 0.f);  // unreachable: the host picks an instantiation that covers the scene
+  return false;
 }
 
 // --------------------------------------------------------------------------------- camera
@@ -743,17 +836,23 @@ RT_DEV Ray camera_ray(const DCamera& cam, const DRender& R, int x, int y, const 
   double t = ((double)y + (double)u24(o4[1])) / (double)(R.height - 1);
   double time_ = cam.time0 + (cam.time1 - cam.time0) * (double)u24(o4[2]);
   // random-in-unit-disk (base.clj:188-194): draw 0 never tested, first later draw inside the disk.
-  double dx = 0.0, dy = 0.0;
-  for (uint32_t k = 1; k < RT_MAX_TRIALS; ++k) {
-    uint32_t d4[4];
-    philox(g, k >> 1, 0, P_DISK, d4);
-    float ux = u24((k & 1) ? d4[2] : d4[0]), uy = u24((k & 1) ? d4[3] : d4[1]);
-    dx = -1.0 + 2.0 * (double)ux;
-    dy = -1.0 + 2.0 * (double)uy;
-    tally.template add<RT_EV_DISK_TRIAL>();
-    if (dx * dx + dy * dy < 1.0) break;
+  // The reference draws it even when the lens radius is 0 (ray.clj:18); the result is then
+  // multiplied by 0, so the addressed draws are simply not generated.
+  double rx = 0.0, ry = 0.0;
+  if (cam.lens_radius != 0.0) {
+    double dx = 0.0, dy = 0.0;
+    for (uint32_t k = 1; k < RT_MAX_TRIALS; ++k) {
+      uint32_t d4[4];
+      philox(g, k >> 1, 0, P_DISK, d4);
+      float ux = u24((k & 1) ? d4[2] : d4[0]), uy = u24((k & 1) ? d4[3] : d4[1]);
+      dx = -1.0 + 2.0 * (double)ux;
+      dy = -1.0 + 2.0 * (double)uy;
+      tally.template add<RT_EV_DISK_TRIAL>();
+      if (dx * dx + dy * dy < 1.0) break;
+    }
+    rx = dx * cam.lens_radius;
+    ry = dy * cam.lens_radius;
   }
-  double rx = dx * cam.lens_radius, ry = dy * cam.lens_radius;
   double off[3], org[3], dir[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {

@@ -21,17 +21,20 @@ namespace rt {
 //   [0, n_perlin*4096)                 Perlin gradient vectors, float4 each
 //   [.., + n_perlin*768 rounded to 16) Perlin permutations, bytes
 //   [.., + blockDim*bvh_stack*4)       per-lane BVH stacks, entry e of lane l at e*blockDim + l
-__device__ __forceinline__ Ctx make_ctx(const DScene& S, unsigned char* lds) {
-  Ctx X;
+template <uint32_t FEAT>
+__device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* lds) {
+  Ctx<FEAT> X;
   X.S = S;
   size_t vec_bytes = (size_t)S.n_perlin * 4096;
   size_t perm_bytes = ((size_t)S.n_perlin * 768 + 15) & ~(size_t)15;
   float4* lv = reinterpret_cast<float4*>(lds);
   uint8_t* lp = lds + vec_bytes;
   const float4* gv = reinterpret_cast<const float4*>(S.perlin_vec);
-  for (int i = threadIdx.x; i < S.n_perlin * 256; i += blockDim.x) lv[i] = gv[i];
-  for (int i = threadIdx.x; i < S.n_perlin * 768; i += blockDim.x) lp[i] = S.perlin_perm[i];
-  __syncthreads();
+  if constexpr ((FEAT & F_TEXTURES) != 0) {
+    for (int i = threadIdx.x; i < S.n_perlin * 256; i += blockDim.x) lv[i] = gv[i];
+    for (int i = threadIdx.x; i < S.n_perlin * 768; i += blockDim.x) lp[i] = S.perlin_perm[i];
+    __syncthreads();
+  }
   X.lds_perlin_vec = reinterpret_cast<const float*>(lv);
   X.lds_perlin_perm = lp;
   X.lds_stack = reinterpret_cast<int*>(lds + vec_bytes + perm_bytes) + threadIdx.x;
@@ -45,8 +48,8 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 
 // One ray-color invocation (core.clj:19-30) for the lane's current path. Returns true when the
 // path ended; `L` is then the radiance of the whole path (throughput already applied).
-template <class T>
-__device__ __forceinline__ bool path_step(const Ctx& X, const DRender& R, Ray& ray, V3& beta, uint32_t& bounce,
+template <class XC, class T>
+__device__ __forceinline__ bool path_step(const XC& X, const DRender& R, Ray& ray, V3& beta, uint32_t& bounce,
                                           const Rng& g, V3& L, T& tally) {
   Rec rec;
   if (!closest_hit(X, ray, 0.001f, __builtin_inff(), g, bounce, nullptr, false, false, rec, tally)) {
@@ -70,12 +73,12 @@ __device__ __forceinline__ bool path_step(const Ctx& X, const DRender& R, Ray& r
   return true;
 }
 
-template <bool COUNT>
+template <uint32_t FEAT, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_render(DScene S, DCamera cam, DRender R, float* __restrict__ out,
                                                      uint32_t* __restrict__ queue,
                                                      unsigned long long* __restrict__ stats) {
   extern __shared__ __align__(16) unsigned char lds[];
-  Ctx X = make_ctx(S, lds);
+  Ctx<FEAT> X = make_ctx<FEAT>(S, lds);
   Tally<COUNT> tally;
   if constexpr (COUNT) tally.clear();
 
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hit_batch(DScene S, int n, const f
                                                         const float* __restrict__ time, float tmin, float tmax,
                                                         const float* __restrict__ medium_xi, rt_hit* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char lds[];
-  Ctx X = make_ctx(S, lds);
+  Ctx<F_ALL> X = make_ctx<F_ALL>(S, lds);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Ray r{mk(orig3[3 * i], orig3[3 * i + 1], orig3[3 * i + 2]), mk(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]),
@@ -234,11 +237,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hit_batch(DScene S, int n, const f
   out[i] = h;
 }
 
+template <uint32_t FEAT>
 __global__ __launch_bounds__(RT_BLOCK) void k_sample_batch(DScene S, DCamera cam, DRender R, int n,
                                                            const int* __restrict__ px, const int* __restrict__ smp,
                                                            float* __restrict__ out_rgb) {
   extern __shared__ __align__(16) unsigned char lds[];
-  Ctx X = make_ctx(S, lds);
+  Ctx<FEAT> X = make_ctx<FEAT>(S, lds);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Tally<false> tally;
@@ -260,20 +264,48 @@ size_t shade_lds_bytes(const DScene& S, int block) {
   return vec_bytes + perm_bytes + (size_t)block * (size_t)S.bvh_stack * 4;
 }
 
+// Kernel instantiations, smallest first. A scene runs on the first one whose mask covers its
+// features: fewer features = fewer registers = more waves per SIMD.
+//   V_RECT   axis-aligned rects under translate/rotate-y chains, solid-colour Lambertians and lights
+//            (the Cornell box)
+//   V_SMOKE  + constant media with isotropic phase functions (the Cornell smoke box)
+//   V_ALL    everything
+constexpr uint32_t V_RECT = F_CHAINS;
+constexpr uint32_t V_SMOKE = F_CHAINS | F_MEDIA;
+constexpr uint32_t V_ALL = F_ALL;
+
+int pick_variant(uint32_t features) {
+  if ((features & ~V_RECT) == 0) return 0;
+  if ((features & ~V_SMOKE) == 0) return 1;
+  return 2;
+}
+
+template <class F>
+auto with_render_kernel(uint32_t features, bool count, F&& f) {
+  switch (pick_variant(features) * 2 + (count ? 1 : 0)) {
+    case 0: return f(k_render<V_RECT, false>);
+    case 1: return f(k_render<V_RECT, true>);
+    case 2: return f(k_render<V_SMOKE, false>);
+    case 3: return f(k_render<V_SMOKE, true>);
+    case 4: return f(k_render<V_ALL, false>);
+    default: return f(k_render<V_ALL, true>);
+  }
+}
+
 hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, float* out, uint32_t* queue,
                          unsigned long long* stats, bool count, int grid, hipStream_t stream) {
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
-  if (count)
-    hipLaunchKernelGGL(k_render<true>, dim3(grid), dim3(RT_BLOCK), lds, stream, S, cam, R, out, queue, stats);
-  else
-    hipLaunchKernelGGL(k_render<false>, dim3(grid), dim3(RT_BLOCK), lds, stream, S, cam, R, out, queue, stats);
-  return hipGetLastError();
+  return with_render_kernel(S.features, count, [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(RT_BLOCK), lds, stream, S, cam, R, out, queue, stats);
+    return hipGetLastError();
+  });
 }
 
 hipError_t render_occupancy(const DScene& S, bool count, int* blocks_per_cu) {
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
-  if (count) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render<true>, RT_BLOCK, lds);
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render<false>, RT_BLOCK, lds);
+  return with_render_kernel(S.features, count, [&](auto kernel) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, RT_BLOCK, lds);
+  });
 }
 
 hipError_t launch_resolve(const DRender& R, const float* partial, float* rgb_sum, uint32_t* argb,
@@ -299,8 +331,12 @@ hipError_t launch_hit_batch(const DScene& S, int n, const float* orig3, const fl
 hipError_t launch_sample_batch(const DScene& S, const DCamera& cam, const DRender& R, int n, const int* px,
                                const int* smp, float* out_rgb, hipStream_t stream) {
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
-  hipLaunchKernelGGL(k_sample_batch, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds, stream, S, cam, R, n,
-                     px, smp, out_rgb);
+  dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
+  switch (pick_variant(S.features)) {  // the same instantiation the render would use
+    case 0: hipLaunchKernelGGL(k_sample_batch<V_RECT>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
+    case 1: hipLaunchKernelGGL(k_sample_batch<V_SMOKE>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
+    default: hipLaunchKernelGGL(k_sample_batch<V_ALL>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
+  }
   return hipGetLastError();
 }
 

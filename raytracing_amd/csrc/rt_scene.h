@@ -23,10 +23,21 @@
 
 enum { DOP_TRANSLATE = 0, DOP_ROTATE_Y = 1 };
 
+// Scene features a kernel instantiation must support (DScene.features, Ctx<FEAT>).
+enum : uint32_t {
+  F_SPHERES = 1,    // sphere / moving-sphere primitives (FP64 quadratic)
+  F_BVH = 2,        // at least one group is traversed through a BVH
+  F_MEDIA = 4,      // constant media (and their isotropic phase functions)
+  F_CHAINS = 8,     // translate / rotate-y wrappers
+  F_TEXTURES = 16,  // checker / noise / image textures
+  F_SPECULAR = 32,  // metal / dielectric
+  F_ALL = 63
+};
+
 // 80 bytes. Spheres are intersected in FP64 (|oc|^2 - r^2 cancels catastrophically in FP32 for
 // the r = 1000 ground spheres), rectangles in FP32.
 struct DPrim {
-  int32_t type;  // RT_PRIM_*
+  int32_t type;  // RT_PRIM_* in bits 0-3, index of the owning group in bits 4-31
   int32_t mat;   // material index of the description
   union {
     double d[9];  // sphere: cx cy cz r | moving sphere: c0 xyz, c1 xyz, t0, t1, r
@@ -71,17 +82,20 @@ struct DBvhNode {
 };
 
 struct DMat {
-  int32_t type;  // RT_MAT_*
+  int32_t type;   // RT_MAT_*
   int32_t tex;
-  int32_t needs_uv;  // its texture (or a checker branch of it) reads u/v: image textures only
+  int32_t flags;  // DMAT_*
   int32_t pad;
-  float r, g, b, x;  // metal: albedo rgb, fuzz | dielectric: r = ir
+  float r, g, b, x;  // metal: albedo rgb, fuzz | dielectric: r = ir | DMAT_SOLID: the texture's colour
 };
+#define DMAT_NEEDS_UV 1  // its texture (or a checker branch of it) reads u/v: image textures only
+#define DMAT_SOLID 2     // its texture is a solid colour, folded into r g b
 
 struct DTex {
   int32_t type;  // RT_TEX_*
   int32_t i0, i1;  // checker: odd, even | noise: perlin id, scale | image: image id
   float r, g, b;   // solid colour
+  int32_t pad[2];
 };
 
 struct DImage {
@@ -108,7 +122,7 @@ struct DScene {
   int32_t n_media;
   int32_t n_perlin;
   int32_t bvh_stack;             // entries per lane the traversal stack needs (0 = no BVH)
-  int32_t pad;
+  uint32_t features;             // F_* mask of what this scene needs from a kernel instantiation
 };
 
 struct DCamera {  // the reference's camera map in FP64 (camera.clj:24-33)
