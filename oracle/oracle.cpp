@@ -157,7 +157,10 @@ struct Rng {
     x = -1.0 + (1.0 - -1.0) * ux;  // random-double mn mx, base.clj:128
     y = -1.0 + (1.0 - -1.0) * uy;
   }
-  // The k-th element of (repeatedly #(random-vec3 -1 1)) at invocation `bounce`.
+  // The k-th element of (repeatedly #(random-vec3 -1 1)) at invocation `bounce`. Keyed stream:
+  // draw 0 is never tested by the reference's reduce, so it is not addressed; draw k >= 1 is
+  // candidate j = k - 1, two candidates per Philox block (block j >> 1, half j & 1), three 21-bit
+  // uniforms each: x, y = top 21 bits of the half's two words, z = the 11 + 10 bits below them.
   V3 sphere_trial(int bounce, int k) {
     double ux, uy, uz;
     if (scripted()) {
@@ -166,10 +169,13 @@ struct Rng {
       uz = next_script();
     } else {
       uint32_t o[4];
-      block(P_SPHERE, bounce, (uint32_t)k, o);
-      ux = u24(o[0]);
-      uy = u24(o[1]);
-      uz = u24(o[2]);
+      int j = k - 1;
+      block(P_SPHERE, bounce, (uint32_t)(j >> 1), o);
+      uint32_t wa = o[(j & 1) * 2], wb = o[(j & 1) * 2 + 1];
+      const double S = 1.0 / 2097152.0;  // 2^-21
+      ux = (double)(wa >> 11) * S;
+      uy = (double)(wb >> 11) * S;
+      uz = (double)(((wa & 0x7FFu) << 10) | ((wb >> 1) & 0x3FFu)) * S;
     }
     return {-1.0 + 2.0 * ux, -1.0 + 2.0 * uy, -1.0 + 2.0 * uz};
   }

@@ -398,12 +398,35 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   bool any_moving = false;
   double tlo = 0.0, thi = 1.0;
   uint32_t features = 0;  // F_* mask
+  std::vector<DGroup64> groups64;
+  // the chain's ray side collapsed to one rigid motion about y: o' = Ry(o) + b (see DGroup)
+  auto chain_motion = [&](int chain, DGroup& G, DGroup64& H) {
+    double c = 1.0, s = 0.0, b[3] = {0.0, 0.0, 0.0};
+    for (const DChainOp& op : F.chains[chain]) {
+      if (op.kind == DOP_TRANSLATE) {
+        b[0] -= op.da; b[1] -= op.db; b[2] -= op.dc;
+      } else {
+        const double so = op.da, co = op.db;
+        const double nc = co * c - so * s, ns = so * c + co * s;
+        const double bx = co * b[0] - so * b[2], bz = so * b[0] + co * b[2];
+        c = nc; s = ns; b[0] = bx; b[2] = bz;
+      }
+    }
+    std::memset(&H, 0, sizeof H);
+    H.rc = c; H.rs = s; H.bx = b[0]; H.by = b[1]; H.bz = b[2];
+    G.rc = (float)c; G.rs = (float)s; G.bx = (float)b[0]; G.by = (float)b[1]; G.bz = (float)b[2];
+  };
   auto emit_groups = [&](const Sink& sink) {
     for (int chain : sink.chain_order) {
-      const std::vector<int>& list = sink.prims.at(chain);
+      std::vector<int> list = sink.prims.at(chain);
+      // by type, stably: XY, XZ, YZ rects, then spheres (scan order kept within a type)
+      auto type_rank = [&](int pi) { int t = d->prim_type[pi]; return t >= RT_PRIM_XY_RECT ? t - RT_PRIM_XY_RECT : 3; };
+      std::stable_sort(list.begin(), list.end(), [&](int x, int y) { return type_rank(x) < type_rank(y); });
       DGroup G;
+      DGroup64 H;
       std::memset(&G, 0, sizeof G);
-      G.chain = chain; G.first_prim = (int)prims.size(); G.n_prims = (int)list.size(); G.bvh_root = -1;
+      G.chain = chain; G.first_prim = (int)prims.size(); G.bvh_root = -1;
+      chain_motion(chain, G, H);
       for (int pi : list) {
         DPrim P;
         std::memset(&P, 0, sizeof P);
@@ -411,8 +434,11 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
         P.type = ptype | ((int)groups.size() << 4);
         P.mat = d->prim_mat[pi];
         const double* pd = d->prim_d + (size_t)pi * RT_PRIM_STRIDE;
-        if (ptype <= RT_PRIM_MOVING_SPHERE) features |= F_SPHERES;
+        if (ptype <= RT_PRIM_MOVING_SPHERE) { features |= F_SPHERES; G.n_sph++; }
         if (ptype <= RT_PRIM_MOVING_SPHERE && chain != 0) G.flags |= DGROUP_SPHERES_UNDER_CHAIN;
+        if (ptype == RT_PRIM_XY_RECT) G.n_xy++;
+        if (ptype == RT_PRIM_XZ_RECT) G.n_xz++;
+        if (ptype == RT_PRIM_YZ_RECT) G.n_yz++;
         if (ptype == RT_PRIM_SPHERE) {
           for (int k = 0; k < 4; ++k) P.d[k] = pd[k];
         } else if (ptype == RT_PRIM_MOVING_SPHERE) {
@@ -426,6 +452,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
         prims.push_back(P);
       }
       groups.push_back(G);
+      groups64.push_back(H);
     }
   };
   emit_groups(F.surface);
@@ -444,6 +471,16 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
       dm.neg_inv_density = M.neg_inv_density;
     }
     dm.n_groups = (int)groups.size() - dm.first_group;  // 0 for a medium the root never reaches
+    {  // an empty group that carries the motion of the chain the medium itself lives under
+      DGroup G;
+      DGroup64 H;
+      std::memset(&G, 0, sizeof G);
+      G.chain = dm.outer_chain; G.first_prim = (int)prims.size(); G.bvh_root = -1;
+      chain_motion(dm.outer_chain, G, H);
+      dm.outer_group = (int)groups.size();
+      groups.push_back(G);
+      groups64.push_back(H);
+    }
     media[m] = dm;
   }
 
@@ -527,8 +564,9 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
 
   // BVHs for the large groups, built on the device
   int n_bvh_nodes = 0;
+  auto group_size = [](const DGroup& G) { return G.n_xy + G.n_xz + G.n_yz + G.n_sph; };
   for (auto& G : groups)
-    if (G.n_prims > RT_BRUTE_MAX) n_bvh_nodes += G.n_prims - 1;
+    if (group_size(G) > RT_BRUTE_MAX) n_bvh_nodes += group_size(G) - 1;
   DBvhNode* d_nodes = nullptr;
   {
     void* p = nullptr;
@@ -539,12 +577,13 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   }
   int node_base = 0, max_height = 0;
   for (auto& G : groups) {
-    if (G.n_prims <= RT_BRUTE_MAX) continue;
+    const int n_prims = group_size(G);
+    if (n_prims <= RT_BRUTE_MAX) continue;
     int height = 0;
-    hipError_t e = build_bvh(d_prims, G.first_prim, G.n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0);
+    hipError_t e = build_bvh(d_prims, G.first_prim, n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e));
     G.bvh_root = node_base;
-    node_base += G.n_prims - 1;
+    node_base += n_prims - 1;
     max_height = std::max(max_height, height);
   }
   S.nodes = d_nodes;
@@ -555,6 +594,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   S.features = features;
 
   if ((rc = upload(sc, groups, &S.groups))) return rc;
+  if ((rc = upload(sc, groups64, &S.groups64))) return rc;
   if ((rc = upload(sc, chains, &S.chains))) return rc;
   if ((rc = upload(sc, ops, &S.ops))) return rc;
   if ((rc = upload(sc, media, &S.media))) return rc;
@@ -566,6 +606,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   if ((rc = upload(sc, texels, &S.texels))) return rc;
   S.n_surface_groups = n_surface_groups;
   S.n_groups = (int)groups.size();
+  S.n_chains = (int)chains.size();
   S.n_media = d->n_media;
   S.n_perlin = d->n_perlin;
 

