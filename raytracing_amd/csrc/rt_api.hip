@@ -399,6 +399,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   double tlo = 0.0, thi = 1.0;
   uint32_t features = 0;  // F_* mask
   std::vector<DGroup64> groups64;
+  std::vector<float> brute_rects;
   // the chain's ray side collapsed to one rigid motion about y: o' = Ry(o) + b (see DGroup)
   auto chain_motion = [&](int chain, DGroup& G, DGroup64& H) {
     double c = 1.0, s = 0.0, b[3] = {0.0, 0.0, 0.0};
@@ -451,6 +452,11 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
         }
         prims.push_back(P);
       }
+      G.first_rect = (int)(brute_rects.size() / RT_RECT_STRIDE);
+      if ((int)list.size() <= RT_BRUTE_MAX)
+        for (size_t q = prims.size() - list.size(); q < prims.size(); ++q)
+          if ((prims[q].type & 15) >= RT_PRIM_XY_RECT)
+            for (int k = 0; k < RT_RECT_STRIDE; ++k) brute_rects.push_back(prims[q].f[k]);
       groups.push_back(G);
       groups64.push_back(H);
     }
@@ -486,9 +492,15 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
 
   std::vector<DChain> chains;
   std::vector<DChainOp> ops;
+  std::vector<DChainRec> chain_recs;
   for (auto& c : F.chains) {
     chains.push_back(DChain{(int)ops.size(), (int)c.size()});
     ops.insert(ops.end(), c.begin(), c.end());
+    DChainRec rec;
+    std::memset(&rec, 0, sizeof rec);
+    rec.n_ops = (int)c.size();
+    for (size_t i = 0; i < c.size(); ++i) { rec.ops[i].kind = c[i].kind; rec.ops[i].a = c[i].a; rec.ops[i].b = c[i].b; rec.ops[i].c = c[i].c; }
+    chain_recs.push_back(rec);
   }
 
   std::vector<DMat> mats((size_t)d->n_mats);
@@ -545,6 +557,21 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
     images[i] = I;
   }
 
+  // per-primitive record / scatter info (one lookup for the winner of a traversal)
+  std::vector<DPrimInfo> infos(prims.size());
+  for (size_t i = 0; i < prims.size(); ++i) {
+    const DPrim& P = prims[i];
+    const DGroup& G = groups[(size_t)(P.type >> 4)];
+    const DMat& M = mats[(size_t)P.mat];
+    DPrimInfo I;
+    std::memset(&I, 0, sizeof I);
+    I.type_group = P.type; I.mat = P.mat; I.chain = G.chain; I.gflags = G.flags;
+    if ((P.type & 15) >= RT_PRIM_XY_RECT) { I.a0 = P.f[0]; I.a1 = P.f[1]; I.b0 = P.f[2]; I.b1 = P.f[3]; I.k = P.f[4]; }
+    I.rc = G.rc; I.rs = G.rs; I.bx = G.bx; I.by = G.by; I.bz = G.bz;
+    I.mtype = M.type; I.mflags = M.flags; I.mtex = M.tex; I.r = M.r; I.g = M.g; I.b = M.b; I.x = M.x;
+    infos[i] = I;
+  }
+
   rt_scene* sc = new (std::nothrow) rt_scene();
   if (!sc) return fail(RT_ERR_OOM, "out of host memory");
   sc->ctx = ctx;
@@ -559,7 +586,14 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
 
   DScene& S = sc->S;
   const DPrim* d_prims = nullptr;
+  const size_t n_real_prims = prims.size();
+  {  // the brute-force loops read primitive records four at a time: keep that much slack
+    DPrim zero;
+    std::memset(&zero, 0, sizeof zero);
+    for (int k = 0; k < 4; ++k) prims.push_back(zero);
+  }
   if ((rc = upload(sc, prims, &d_prims))) return rc;
+  prims.resize(n_real_prims);
   S.prims = d_prims;
 
   // BVHs for the large groups, built on the device
@@ -593,9 +627,14 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   if (chains.size() > 1) features |= F_CHAINS;
   S.features = features;
 
+  brute_rects.resize(brute_rects.size() + RT_RECT_STRIDE * RT_RECT_BATCH, 0.f);  // slack for batched reads
+  if ((rc = upload(sc, brute_rects, &S.brute_rects))) return rc;
+  if ((rc = upload(sc, infos, &S.prim_info))) return rc;
+  S.n_prims = (int)prims.size();
   if ((rc = upload(sc, groups, &S.groups))) return rc;
   if ((rc = upload(sc, groups64, &S.groups64))) return rc;
   if ((rc = upload(sc, chains, &S.chains))) return rc;
+  if ((rc = upload(sc, chain_recs, &S.chain_recs))) return rc;
   if ((rc = upload(sc, ops, &S.ops))) return rc;
   if ((rc = upload(sc, media, &S.media))) return rc;
   if ((rc = upload(sc, mats, &S.mats))) return rc;

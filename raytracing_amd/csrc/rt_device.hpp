@@ -156,11 +156,15 @@ RT_DEV V3 random_unit_vector(const Rng& g, uint32_t bounce, T& tally) {  // base
 }
 
 // ------------------------------------------------------------------------ scene context
+#define RT_LDS __attribute__((address_space(3)))
+
 template <uint32_t FEAT>
 struct Ctx {
   static constexpr uint32_t feat = FEAT;
   static constexpr bool has(uint32_t f) { return (FEAT & f) != 0; }
   DScene S;
+  const DPrimInfo RT_LDS* lds_info;    // F_SMALL: the scene's DPrimInfo table in LDS
+  const DChainRec RT_LDS* lds_chains;  // F_SMALL: its chain records in LDS
   const float* lds_perlin_vec;      // n_perlin * 1024 floats (LDS)
   const uint8_t* lds_perlin_perm;   // n_perlin * 768 bytes (LDS)
   int* lds_stack;                   // BVH stack base of this lane (stride = blockDim.x)
@@ -208,7 +212,15 @@ RT_DEV bool rect_ok(float a0, float a1, float b0, float b1, float k, const RayX&
   else { oc = r.o.x; ic = r.inv.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
   t = (k - oc) * ic;
   float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
+#ifdef RT_RECT_CMP_CHAIN
   return !(t < tmin) & !(t > tmax) & !(a < a0) & !(a > a1) & !(b < b0) & !(b > b1);
+#else
+  // One signed "outside distance" instead of six compares chained through scalar masks: each of
+  // the six terms is > 0 exactly when the reference's rejecting comparison holds; fmaxf drops a
+  // NaN term, as the reference's comparisons let a NaN pass.
+  float m = fmaxf(fmaxf(fmaxf(a0 - a, a - a1), fmaxf(b0 - b, b - b1)), fmaxf(tmin - t, t - tmax));
+  return !(m > 0.0f);
+#endif
 }
 
 template <class PRIM>
@@ -307,12 +319,13 @@ RT_DEV void test_prim_any_order(const DScene& S, int idx, const RayX& r, float t
 // (translate.clj:11, rotate.clj:18-27). Groups with spheres below a chain get the motion in FP64
 // on the exact FP32 world ray, split into an FP32 value and an FP32 residual, so the FP64 sphere
 // test sees what the reference sees. G is wave-uniform in the traversal loops (SGPR operands).
-template <class X, class GROUP, class T>
-RT_DEV RayX group_ray(const DScene& S, int g, const GROUP& G, const Ray& wr, T& tally) {
+template <class X, class T>
+RT_DEV RayX group_ray(const DScene& S, int g, int gflags, float rc, float rs, float bx, float by, float bz,
+                      const Ray& wr, T& tally) {
   if constexpr (!X::has(F_CHAINS)) {
     return make_rayx(wr.o, wr.d, wr.tm);
   } else {
-    if (X::has(F_SPHERES) && (G.flags & DGROUP_SPHERES_UNDER_CHAIN)) {
+    if (X::has(F_SPHERES) && (gflags & DGROUP_SPHERES_UNDER_CHAIN)) {
       const DGroup64 RT_CONST& H = cptr(S.groups64)[g];
       const double c = H.rc, s = H.rs;
       D3 wo = tod(wr.o), wd = tod(wr.d);
@@ -324,9 +337,9 @@ RT_DEV RayX group_ray(const DScene& S, int g, const GROUP& G, const Ray& wr, T& 
       r.d_lo = mk((float)(d.x - (double)r.d.x), (float)(d.y - (double)r.d.y), (float)(d.z - (double)r.d.z));
       return r;
     }
-    const float c = G.rc, s = G.rs;
+    const float c = rc, s = rs;
     // explicit FMAs: every inlined copy must round identically
-    V3 o = mk(fmaf(c, wr.o.x, fmaf(-s, wr.o.z, G.bx)), wr.o.y + G.by, fmaf(s, wr.o.x, fmaf(c, wr.o.z, G.bz)));
+    V3 o = mk(fmaf(c, wr.o.x, fmaf(-s, wr.o.z, bx)), wr.o.y + by, fmaf(s, wr.o.x, fmaf(c, wr.o.z, bz)));
     V3 d = mk(fmaf(c, wr.d.x, -(s * wr.d.z)), wr.d.y, fmaf(s, wr.d.x, c * wr.d.z));
     tally.template add<RT_EV_ROTATE_RAY>();
     return make_rayx(o, d, wr.tm);
@@ -390,17 +403,36 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
   }
 }
 
-// One homogeneous run of rects of a brute-force group: no type dispatch, records in SGPRs.
-template <int TYPE, class T>
-RT_DEV void rect_run(const DPrim RT_CONST* prims, int first, int n, const RayX& r, float tmin, Best& best, T& tally) {
-#pragma unroll 2
-  for (int i = 0; i < n; ++i) {
-    const DPrim RT_CONST& P = prims[first + i];
-    float t;
-    tally.template add<RT_EV_RECT_TEST>();
-    bool ok = rect_ok<TYPE>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
-    best.t = ok ? t : best.t;
-    best.prim = ok ? first + i : best.prim;
+// The rects of a brute-force group, stored by type (XY, XZ, YZ). RT_RECT_BATCH records are
+// fetched per trip with unconditional scalar loads (the table carries that much slack) and pinned
+// in SGPRs before any of them is used, so a box costs one scalar-memory round trip, not six.
+template <class T>
+RT_DEV void brute_rects(const float RT_CONST* R, int first_prim, int n_xy, int n_xz, int n_yz, const RayX& r,
+                        float tmin, Best& best, T& tally) {
+  const int n = n_xy + n_xz + n_yz;
+  for (int base = 0; base < n; base += RT_RECT_BATCH) {
+    float v[RT_RECT_BATCH * RT_RECT_STRIDE];
+#pragma unroll
+    for (int q = 0; q < RT_RECT_BATCH * RT_RECT_STRIDE; ++q) v[q] = R[base * RT_RECT_STRIDE + q];
+    asm volatile("" ::"s"(v[0]), "s"(v[1]), "s"(v[2]), "s"(v[3]), "s"(v[4]), "s"(v[5]), "s"(v[6]), "s"(v[7]), "s"(v[8]),
+                 "s"(v[9]), "s"(v[10]), "s"(v[11]), "s"(v[12]), "s"(v[13]), "s"(v[14]), "s"(v[15]), "s"(v[16]),
+                 "s"(v[17]), "s"(v[18]), "s"(v[19]), "s"(v[20]), "s"(v[21]), "s"(v[22]), "s"(v[23]), "s"(v[24]),
+                 "s"(v[25]), "s"(v[26]), "s"(v[27]), "s"(v[28]), "s"(v[29]));
+#pragma unroll
+    for (int j = 0; j < RT_RECT_BATCH; ++j) {
+      const int idx = base + j;
+      if (idx < n) {  // wave-uniform, as is the type of the record
+        const float* w = v + j * RT_RECT_STRIDE;
+        float t;
+        bool ok;
+        tally.template add<RT_EV_RECT_TEST>();
+        if (idx < n_xy) ok = rect_ok<RT_PRIM_XY_RECT>(w[0], w[1], w[2], w[3], w[4], r, tmin, best.t, t);
+        else if (idx < n_xy + n_xz) ok = rect_ok<RT_PRIM_XZ_RECT>(w[0], w[1], w[2], w[3], w[4], r, tmin, best.t, t);
+        else ok = rect_ok<RT_PRIM_YZ_RECT>(w[0], w[1], w[2], w[3], w[4], r, tmin, best.t, t);
+        best.t = ok ? t : best.t;
+        best.prim = ok ? first_prim + idx : best.prim;
+      }
+    }
   }
 }
 
@@ -409,7 +441,7 @@ template <class X, class T>
 RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best, T& tally) {
   const DScene& S = ctx.S;
   const DGroup RT_CONST& G = cptr(S.groups)[g];
-  const RayX r = group_ray<X>(S, g, G, wr, tally);
+  const RayX r = group_ray<X>(S, g, G.flags, G.rc, G.rs, G.bx, G.by, G.bz, wr, tally);
   const int bvh_root = G.bvh_root;
   if (X::has(F_BVH) && bvh_root >= 0) {
     if constexpr (X::has(F_BVH)) bvh_traverse(ctx, bvh_root, r, tmin, best, tally);
@@ -417,12 +449,8 @@ RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best
     const DPrim RT_CONST* prims = cptr(S.prims);
     int first = G.first_prim;
     const int n_xy = G.n_xy, n_xz = G.n_xz, n_yz = G.n_yz;
-    rect_run<RT_PRIM_XY_RECT>(prims, first, n_xy, r, tmin, best, tally);
-    first += n_xy;
-    rect_run<RT_PRIM_XZ_RECT>(prims, first, n_xz, r, tmin, best, tally);
-    first += n_xz;
-    rect_run<RT_PRIM_YZ_RECT>(prims, first, n_yz, r, tmin, best, tally);
-    first += n_yz;
+    brute_rects(cptr(S.brute_rects) + G.first_rect * RT_RECT_STRIDE, first, n_xy, n_xz, n_yz, r, tmin, best, tally);
+    first += n_xy + n_xz + n_yz;
     if constexpr (X::has(F_SPHERES)) {
       const int n_sph = G.n_sph;
       for (int i = 0; i < n_sph; ++i) {
@@ -438,12 +466,33 @@ RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best
 }
 
 // ------------------------------------------------------------------------------ records
-struct Rec {  // base.clj:169
+struct Rec {  // base.clj:169, plus the fields of its material (mat-ptr dereferenced once)
   V3 p, n;
   float t, u, v;
   int mat;
   bool front;
+  int mtype, mflags, mtex;
+  V3 rgb;
+  float mx;
 };
+
+template <class PTR>
+RT_DEV DPrimInfo fetch_info(PTR p) {
+  DPrimInfo I;
+  I.type_group = p->type_group; I.mat = p->mat; I.chain = p->chain; I.gflags = p->gflags;
+  I.a0 = p->a0; I.a1 = p->a1; I.b0 = p->b0; I.b1 = p->b1;
+  I.k = p->k; I.rc = p->rc; I.rs = p->rs; I.bx = p->bx; I.by = p->by; I.bz = p->bz;
+  I.mtype = p->mtype; I.mflags = p->mflags; I.mtex = p->mtex;
+  I.r = p->r; I.g = p->g; I.b = p->b; I.x = p->x;
+  return I;
+}
+// Everything about primitive `prim` that its record and scatter need: one round trip, to LDS
+// for small scenes.
+template <class X>
+RT_DEV DPrimInfo load_info(const X& ctx, int prim) {
+  if constexpr (X::has(F_SMALL)) return fetch_info(ctx.lds_info + prim);
+  else return fetch_info(cptr(ctx.S.prim_info) + prim);
+}
 
 // base.clj:222-227 in FP64 (acos is ill-conditioned at the poles).
 RT_DEV void sphere_uv(D3 n, float& u, float& v) {
@@ -454,20 +503,21 @@ RT_DEV void sphere_uv(D3 n, float& u, float& v) {
   v = (float)(theta / PI);
 }
 
-// The HitRecord of primitive `prim` for the (chain-space) ray r at parameter t.
+// The HitRecord of primitive `prim` (info I) for the (chain-space) ray r at parameter t.
 template <class X, class T>
-RT_DEV void prim_record(const DScene& S, int prim, const RayX& r, float t, bool second_root, bool want_uv,
-                        Rec& rec, T& tally) {
-  const DPrim RT_CONST& P = cptr(S.prims)[prim];
-  const int type = prim_type(P.type);
-  rec.mat = P.mat;
+RT_DEV void prim_record(const DScene& S, int prim, const DPrimInfo& I, const RayX& r, float t, bool second_root,
+                        bool want_uv, Rec& rec, T& tally) {
+  const int type = prim_type(I.type_group);
+  rec.mat = I.mat;
+  rec.mtype = I.mtype; rec.mflags = I.mflags; rec.mtex = I.mtex;
+  rec.rgb = mk(I.r, I.g, I.b); rec.mx = I.x;
   rec.t = t;
   rec.u = rec.v = 0.f;
   if (!X::has(F_SPHERES) || is_rect(type)) {
     // rectangles.clj:31-37; the in-plane point is o + t d, the constant coordinate is set to k
     // (in FP64 the reference's o + t d lands on k to 1e-13; FP32 rounding would not).
     tally.template add<RT_EV_RECT_RECORD>();
-    const float k = P.f[4];
+    const float k = I.k;
     V3 p = mk(fmaf(t, r.d.x, r.o.x), fmaf(t, r.d.y, r.o.y), fmaf(t, r.d.z, r.o.z));
     float a, b, dn;
     V3 out;
@@ -475,8 +525,8 @@ RT_DEV void prim_record(const DScene& S, int prim, const RayX& r, float t, bool 
     else if (type == RT_PRIM_XZ_RECT) { p.y = k; a = p.x; b = p.z; dn = r.d.y; out = mk(0, 1, 0); }
     else { p.x = k; a = p.y; b = p.z; dn = r.d.x; out = mk(1, 0, 0); }
     if (want_uv) {
-      rec.u = (a - P.f[0]) / (P.f[1] - P.f[0]);
-      rec.v = (b - P.f[2]) / (P.f[3] - P.f[2]);
+      rec.u = (a - I.a0) / (I.a1 - I.a0);
+      rec.v = (b - I.b0) / (I.b1 - I.b0);
     }
     rec.front = dn < 0.0f;  // set-face-normal, base.clj:171-174
     rec.n = rec.front ? out : neg(out);
@@ -485,6 +535,7 @@ RT_DEV void prim_record(const DScene& S, int prim, const RayX& r, float t, bool 
     if constexpr (X::has(F_SPHERES)) {
       // base.clj:243-246 in FP64 from the FP64 root (recomputed: only the winner pays for it)
       tally.template add<RT_EV_SPHERE_RECORD>();
+      const DPrim RT_CONST& P = cptr(S.prims)[prim];
       Tally<false> quiet;
       double root1 = (double)t, root2 = (double)t;
       sphere_roots(P, type, r, root1, root2, quiet);
@@ -504,63 +555,52 @@ RT_DEV void prim_record(const DScene& S, int prim, const RayX& r, float t, bool 
 
 // Record fix-ups on the way back up a chain: rotate.clj:31-47 (both components use +sin, and the
 // face test is against the ROTATED ray) then translate.clj:13-17 (face test against the moved
-// ray, whose direction is the outer one).
-template <class X, class T>
-RT_DEV void chain_unwind_one(const DScene& S, int chain, V3 world_d, Rec& rec, T& tally) {
-  if constexpr (X::has(F_CHAINS)) {
-    const DChain RT_CONST* chains = cptr(S.chains);
-    const DChainOp RT_CONST* ops = cptr(S.ops);
-    const int first_op = chains[chain].first_op, n_ops = chains[chain].n_ops;
-    if (n_ops == 0) return;
-    V3 dirs[RT_MAX_CHAIN_OPS + 1];
-    dirs[0] = world_d;
+// ray, whose direction is the outer one). CHAIN points at the chain's record (LDS for small
+// scenes); the chain differs per lane.
+template <class X, class CHAIN, class T>
+RT_DEV void chain_unwind_rec(CHAIN C, V3 world_d, Rec& rec, T& tally) {
+  const int n_ops = C->n_ops;
+  if (n_ops == 0) return;
+  int kind[RT_MAX_CHAIN_OPS];
+  float oa[RT_MAX_CHAIN_OPS], ob[RT_MAX_CHAIN_OPS], oc[RT_MAX_CHAIN_OPS];
 #pragma unroll
-    for (int i = 0; i < RT_MAX_CHAIN_OPS; ++i) {
-      V3 d = dirs[i];
-      if (i < n_ops) {
-        const DChainOp RT_CONST& op = ops[first_op + i];
-        if (op.kind == DOP_ROTATE_Y) d = mk(fmaf(op.b, d.x, -(op.a * d.z)), d.y, fmaf(op.a, d.x, op.b * d.z));
-      }
-      dirs[i + 1] = d;
-    }
+  for (int i = 0; i < RT_MAX_CHAIN_OPS; ++i) { kind[i] = C->ops[i].kind; oa[i] = C->ops[i].a; ob[i] = C->ops[i].b; oc[i] = C->ops[i].c; }
+  V3 dirs[RT_MAX_CHAIN_OPS + 1];
+  dirs[0] = world_d;
 #pragma unroll
-    for (int i = RT_MAX_CHAIN_OPS - 1; i >= 0; --i) {
-      if (i < n_ops) {
-        const DChainOp RT_CONST& op = ops[first_op + i];
-        V3 d_inner = dirs[i + 1];
-        if (op.kind == DOP_ROTATE_Y) {
-          float s = op.a, c = op.b;
-          V3 p = rec.p, n = rec.n;
-          rec.p = mk(fmaf(c, p.x, s * p.z), p.y, fmaf(s, p.x, c * p.z));
-          V3 nn = mk(fmaf(c, n.x, s * n.z), n.y, fmaf(s, n.x, c * n.z));
-          rec.front = dot(d_inner, nn) < 0.0f;
-          rec.n = rec.front ? nn : neg(nn);
-          tally.template add<RT_EV_ROTATE_REC>();
-        } else {
-          rec.front = dot(d_inner, rec.n) < 0.0f;
-          rec.n = rec.front ? rec.n : neg(rec.n);
-          rec.p = mk(rec.p.x + op.a, rec.p.y + op.b, rec.p.z + op.c);
-          tally.template add<RT_EV_TRANSLATE_REC>();
-        }
+  for (int i = 0; i < RT_MAX_CHAIN_OPS; ++i) {
+    V3 d = dirs[i];
+    if (i < n_ops && kind[i] == DOP_ROTATE_Y) d = mk(fmaf(ob[i], d.x, -(oa[i] * d.z)), d.y, fmaf(oa[i], d.x, ob[i] * d.z));
+    dirs[i + 1] = d;
+  }
+#pragma unroll
+  for (int i = RT_MAX_CHAIN_OPS - 1; i >= 0; --i) {
+    if (i < n_ops) {
+      V3 d_inner = dirs[i + 1];
+      if (kind[i] == DOP_ROTATE_Y) {
+        float s = oa[i], c = ob[i];
+        V3 p = rec.p, n = rec.n;
+        rec.p = mk(fmaf(c, p.x, s * p.z), p.y, fmaf(s, p.x, c * p.z));
+        V3 nn = mk(fmaf(c, n.x, s * n.z), n.y, fmaf(s, n.x, c * n.z));
+        rec.front = dot(d_inner, nn) < 0.0f;
+        rec.n = rec.front ? nn : neg(nn);
+        tally.template add<RT_EV_ROTATE_REC>();
+      } else {
+        rec.front = dot(d_inner, rec.n) < 0.0f;
+        rec.n = rec.front ? rec.n : neg(rec.n);
+        rec.p = mk(rec.p.x + oa[i], rec.p.y + ob[i], rec.p.z + oc[i]);
+        tally.template add<RT_EV_TRANSLATE_REC>();
       }
     }
   }
 }
 
-// With few chains the walk is done once per chain with a wave-uniform chain index (operations in
-// SGPRs, no per-lane loads); lanes whose record lives under that chain take part.
 template <class X, class T>
-RT_DEV void chain_unwind(const DScene& S, int chain, V3 world_d, Rec& rec, T& tally) {
+RT_DEV void chain_unwind(const X& ctx, int chain, V3 world_d, Rec& rec, T& tally) {
   if constexpr (X::has(F_CHAINS)) {
-    const int n_chains = S.n_chains;
-    if (n_chains <= 9) {
-      for (int c = 1; c < n_chains; ++c) {
-        if (__ballot(chain == c) == 0ull) continue;
-        if (chain == c) chain_unwind_one<X>(S, c, world_d, rec, tally);
-      }
-    } else {
-      chain_unwind_one<X>(S, chain, world_d, rec, tally);
-    }
+    if (chain == 0) return;
+    if constexpr (X::has(F_SMALL)) chain_unwind_rec<X>(ctx.lds_chains + chain, world_d, rec, tally);
+    else chain_unwind_rec<X>(cptr(ctx.S.chain_recs) + chain, world_d, rec, tally);
   }
 }
 
@@ -608,11 +648,15 @@ RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax,
 // skip_media drops MEDIUM nodes altogether.
 template <class X, class T>
 RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, const Rng& g, uint32_t bounce,
-                        const float* medium_xi, bool skip_media, bool want_uv_always, Rec& rec, T& tally) {
+                        const float* medium_xi, bool skip_media, bool want_uv_always, Rec& rec, T& tally,
+                        unsigned long long* g_stamp_inner = nullptr) {
   const DScene& S = ctx.S;
   Best best{tmax, -1};
   const int n_surface = S.n_surface_groups;
   for (int gi = 0; gi < n_surface; ++gi) group_hit(ctx, gi, wr, tmin, best, tally);
+#ifdef RT_STAMPS
+  if (g_stamp_inner) { __builtin_amdgcn_sched_barrier(0); *g_stamp_inner = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#endif
   if constexpr (X::has(F_MEDIA)) {
     if (!skip_media) {
       const int n_media = S.n_media;
@@ -629,29 +673,30 @@ RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, con
   if (!X::has(F_MEDIA) || best.prim >= 0) {
     const bool second_root = (best.prim & RT_SECOND_ROOT) != 0;
     const int prim = best.prim & ~RT_SECOND_ROOT;
-    const int group = prim_group(cptr(S.prims)[prim].type);
-    const DGroup RT_CONST& G = cptr(S.groups)[group];
-    const int chain = G.chain;
-    RayX rx = group_ray<X>(S, group, G, wr, tally);
+    const DPrimInfo I = load_info(ctx, prim);
+    RayX rx = group_ray<X>(S, prim_group(I.type_group), I.gflags, I.rc, I.rs, I.bx, I.by, I.bz, wr, tally);
     bool want_uv = want_uv_always;
-    if constexpr (X::has(F_TEXTURES))
-      want_uv = want_uv || (cptr(S.mats)[cptr(S.prims)[prim].mat].flags & DMAT_NEEDS_UV) != 0;
-    prim_record<X>(S, prim, rx, best.t, second_root, want_uv, rec, tally);
-    chain_unwind<X>(S, chain, wr.d, rec, tally);
+    if constexpr (X::has(F_TEXTURES)) want_uv = want_uv || (I.mflags & DMAT_NEEDS_UV) != 0;
+    prim_record<X>(S, prim, I, rx, best.t, second_root, want_uv, rec, tally);
+    chain_unwind(ctx, I.chain, wr.d, rec, tally);
   } else {
     if constexpr (X::has(F_MEDIA)) {
       // constant_medium.clj:38-44: p = ray-at r t, normal [1 0 0], front-face true, no u/v
       const DMedium RT_CONST& M = cptr(S.media)[-2 - best.prim];
       const int outer = M.outer_chain;
       // the medium's own space: its outer chain's motion, kept in a one-group header per medium
-      RayX mr = group_ray<X>(S, M.outer_group, cptr(S.groups)[M.outer_group], wr, tally);
+      const DGroup RT_CONST& OG = cptr(S.groups)[M.outer_group];
+      RayX mr = group_ray<X>(S, M.outer_group, 0, OG.rc, OG.rs, OG.bx, OG.by, OG.bz, wr, tally);
       rec.t = best.t;
       rec.p = mk(fmaf(best.t, mr.d.x, mr.o.x), fmaf(best.t, mr.d.y, mr.o.y), fmaf(best.t, mr.d.z, mr.o.z));
       rec.n = mk(1.f, 0.f, 0.f);
       rec.front = true;
       rec.mat = M.phase_mat;
+      const DMat RT_CONST& PM = cptr(S.mats)[M.phase_mat];
+      rec.mtype = PM.type; rec.mflags = PM.flags; rec.mtex = PM.tex;
+      rec.rgb = mk(PM.r, PM.g, PM.b); rec.mx = PM.x;
       rec.u = rec.v = 0.f;
-      chain_unwind<X>(S, outer, wr.d, rec, tally);
+      chain_unwind(ctx, outer, wr.d, rec, tally);
     }
   }
   return true;
@@ -785,9 +830,8 @@ RT_DEV float reflectance(float cosine, float ref_idx) {  // base.clj:215-220
 template <class X, class T>
 RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t bounce, V3& attenuation,
                     V3& emitted, T& tally) {
-  const DMat RT_CONST& M = cptr(ctx.S.mats)[rec.mat];
-  const int type = M.type, flags = M.flags, tex = M.tex;
-  const V3 rgb = mk(M.r, M.g, M.b);
+  const int type = rec.mtype, flags = rec.mflags, tex = rec.mtex;
+  const V3 rgb = rec.rgb;
   emitted = mk(0.f, 0.f, 0.f);
   if (type == RT_MAT_LAMBERTIAN) {  // :16-23
     tally.template add<RT_EV_LAMBERT>();
@@ -806,14 +850,14 @@ RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t
     if (type == RT_MAT_METAL) {  // :33-39
       tally.template add<RT_EV_METAL>();
       V3 reflected = reflect(unit(r.d), rec.n);
-      V3 dir = madd(random_in_unit_sphere(g, bounce, tally), M.x, reflected);
+      V3 dir = madd(random_in_unit_sphere(g, bounce, tally), rec.mx, reflected);
       attenuation = rgb;
       r.o = rec.p; r.d = dir;
       return dot(dir, rec.n) > 0.0f;
     }
     if (type == RT_MAT_DIELECTRIC) {  // :47-61
       tally.template add<RT_EV_DIELECTRIC>();
-      float ir = M.r;
+      float ir = rec.rgb.x;
       float ratio = rec.front ? (1.0f / ir) : ir;
       V3 ud = unit(r.d);
       float cos_theta = fminf(dot(neg(ud), rec.n), 1.0f);

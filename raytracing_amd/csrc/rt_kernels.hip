@@ -24,6 +24,7 @@ namespace rt {
 // Dynamic LDS layout shared by all kernels that shade:
 //   [0, n_perlin*4096)                 Perlin gradient vectors, float4 each
 //   [.., + n_perlin*768 rounded to 16) Perlin permutations, bytes
+//   [.., + n_prims*96 + n_chains*80)   DPrimInfo and DChainRec tables (F_SMALL instantiations only)
 //   [.., + blockDim*bvh_stack*4)       per-lane BVH stacks, entry e of lane l at e*blockDim + l
 template <uint32_t FEAT>
 __device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* lds) {
@@ -34,14 +35,30 @@ __device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* ld
   float4* lv = reinterpret_cast<float4*>(lds);
   uint8_t* lp = lds + vec_bytes;
   const float4* gv = reinterpret_cast<const float4*>(S.perlin_vec);
+  size_t info_bytes = 0;
   if constexpr ((FEAT & F_TEXTURES) != 0) {
     for (int i = threadIdx.x; i < S.n_perlin * 256; i += blockDim.x) lv[i] = gv[i];
     for (int i = threadIdx.x; i < S.n_perlin * 768; i += blockDim.x) lp[i] = S.perlin_perm[i];
-    __syncthreads();
   }
+  X.lds_info = nullptr;
+  X.lds_chains = nullptr;
+  if constexpr ((FEAT & F_SMALL) != 0) {
+    const size_t pi_bytes = (size_t)S.n_prims * sizeof(DPrimInfo);
+    const size_t ch_bytes = (size_t)S.n_chains * sizeof(DChainRec);
+    info_bytes = pi_bytes + ch_bytes;
+    uint4* li = reinterpret_cast<uint4*>(lds + vec_bytes + perm_bytes);
+    const uint4* gi = reinterpret_cast<const uint4*>(S.prim_info);
+    for (int i = threadIdx.x; i < (int)(pi_bytes / 16); i += blockDim.x) li[i] = gi[i];
+    uint4* lc = reinterpret_cast<uint4*>(lds + vec_bytes + perm_bytes + pi_bytes);
+    const uint4* gc = reinterpret_cast<const uint4*>(S.chain_recs);
+    for (int i = threadIdx.x; i < (int)(ch_bytes / 16); i += blockDim.x) lc[i] = gc[i];
+    X.lds_info = (const DPrimInfo RT_LDS*)(lds + vec_bytes + perm_bytes);
+    X.lds_chains = (const DChainRec RT_LDS*)(lds + vec_bytes + perm_bytes + pi_bytes);
+  }
+  if constexpr ((FEAT & (F_TEXTURES | F_SMALL)) != 0) __syncthreads();
   X.lds_perlin_vec = reinterpret_cast<const float*>(lv);
   X.lds_perlin_perm = lp;
-  X.lds_stack = reinterpret_cast<int*>(lds + vec_bytes + perm_bytes) + threadIdx.x;
+  X.lds_stack = reinterpret_cast<int*>(lds + vec_bytes + perm_bytes + info_bytes) + threadIdx.x;
   X.stack_stride = blockDim.x;
   return X;
 }
@@ -52,11 +69,24 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 
 // One ray-color invocation (core.clj:19-30) for the lane's current path. Returns true when the
 // path ended; `L` is then the radiance of the whole path (throughput already applied).
+// Diagnostic build only (-DRT_STAMPS): wave-cycle shares of the loop phases, accumulated per wave
+// and written over the event slots of the stats buffer. Never timed, never shipped.
+#ifdef RT_STAMPS
+#define RT_STAMP(var) { __builtin_amdgcn_sched_barrier(0); var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define RT_STAMP(var)
+#endif
+
 template <class XC, class T>
 __device__ __forceinline__ bool path_step(const XC& X, const DRender& R, Ray& ray, V3& beta, uint32_t& bounce,
-                                          const Rng& g, V3& L, T& tally) {
+                                          const Rng& g, V3& L, T& tally, unsigned long long* stamp_mid = nullptr,
+                                          unsigned long long* stamp_inner = nullptr) {
   Rec rec;
-  if (!closest_hit(X, ray, 0.001f, __builtin_inff(), g, bounce, nullptr, false, false, rec, tally)) {
+  bool hit = closest_hit(X, ray, 0.001f, __builtin_inff(), g, bounce, nullptr, false, false, rec, tally, stamp_inner);
+#ifdef RT_STAMPS
+  if (stamp_mid) RT_STAMP(*stamp_mid);
+#endif
+  if (!hit) {
     L = beta * mk(R.bg[0], R.bg[1], R.bg[2]);  // core.clj:30
     tally.template add<RT_EV_THROUGHPUT>();
     return true;
@@ -112,7 +142,11 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
   Rng g{0u, 0u, R.seed_lo, R.seed_hi};
   uint32_t n_rays = 0, n_samples = 0;
 
+#ifdef RT_STAMPS
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsi = 0, c_queue = 0, c_cam = 0, c_hit = 0, c_shade = 0, c_iters = 0, c_groups = 0;
+#endif
   for (;;) {
+    RT_STAMP(ts0);
     bool need = !active && !done && !(have_item && s < s_end);
     if (need && have_item) {
       // core.clj:115-120 finished for this chunk: store the partial sum of its samples
@@ -158,6 +192,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       }
       q_next += min(cnt, avail);
     }
+    RT_STAMP(ts1);
     if (!active && have_item && s < s_end) {
       // core.clj:96-105: a fresh camera path for sample s of this pixel
       g.k0 = (uint32_t)pix;
@@ -174,16 +209,34 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       }
     }
     if (__ballot(!done) == 0ull) break;
+    RT_STAMP(ts2);
+#ifdef RT_STAMPS
+    ts3 = ts2; tsi = ts2;
+#endif
     if (active) {
       V3 L;
       ++n_rays;
+#ifdef RT_STAMPS
+      if (path_step(X, R, ray, beta, bounce, g, L, tally, &ts3, &tsi)) {
+#else
       if (path_step(X, R, ray, beta, bounce, g, L, tally)) {
+#endif
         acc = acc + L;  // core.clj:120
         tally.template add<RT_EV_ACCUMULATE>();
         active = false;
       }
     }
+#ifdef RT_STAMPS
+    RT_STAMP(ts4);
+    c_queue += ts1 - ts0; c_cam += ts2 - ts1; c_hit += ts3 - ts2; c_shade += ts4 - ts3; c_iters += 1; c_groups += tsi - ts2;
+#endif
   }
+#ifdef RT_STAMPS
+  if (lane == 0) {
+    atomicAdd(&stats[2 + 0], c_queue); atomicAdd(&stats[2 + 1], c_cam); atomicAdd(&stats[2 + 2], c_hit);
+    atomicAdd(&stats[2 + 3], c_shade); atomicAdd(&stats[2 + 4], c_iters); atomicAdd(&stats[2 + 5], c_groups);
+  }
+#endif
   atomicAdd(&stats[0], (unsigned long long)n_samples);
   atomicAdd(&stats[1], (unsigned long long)n_rays);
   if constexpr (COUNT) {
@@ -269,31 +322,33 @@ __global__ __launch_bounds__(RT_BLOCK) void k_sample_batch(DScene S, DCamera cam
 }
 
 // ------------------------------------------------------------------------------ launchers
-size_t shade_lds_bytes(const DScene& S, int block) {
-  size_t vec_bytes = (size_t)S.n_perlin * 4096;
-  size_t perm_bytes = ((size_t)S.n_perlin * 768 + 15) & ~(size_t)15;
-  return vec_bytes + perm_bytes + (size_t)block * (size_t)S.bvh_stack * 4;
-}
-
 // Kernel instantiations, smallest first. A scene runs on the first one whose mask covers its
 // features: fewer features = fewer registers = more waves per SIMD.
 //   V_RECT   axis-aligned rects under translate/rotate-y chains, solid-colour Lambertians and lights
 //            (the Cornell box)
 //   V_SMOKE  + constant media with isotropic phase functions (the Cornell smoke box)
 //   V_ALL    everything
-constexpr uint32_t V_RECT = F_CHAINS;
-constexpr uint32_t V_SMOKE = F_CHAINS | F_MEDIA;
+constexpr uint32_t V_RECT = F_CHAINS | F_SMALL;
+constexpr uint32_t V_SMOKE = F_CHAINS | F_MEDIA | F_SMALL;
 constexpr uint32_t V_ALL = F_ALL;
 
-int pick_variant(uint32_t features) {
-  if ((features & ~V_RECT) == 0) return 0;
-  if ((features & ~V_SMOKE) == 0) return 1;
+int pick_variant(const DScene& S) {
+  const bool small = S.n_prims <= RT_LDS_PRIMS && S.n_chains <= RT_LDS_CHAINS;
+  if (small && (S.features & ~V_RECT) == 0) return 0;
+  if (small && (S.features & ~V_SMOKE) == 0) return 1;
   return 2;
 }
 
+size_t shade_lds_bytes(const DScene& S, int block) {
+  size_t vec_bytes = (size_t)S.n_perlin * 4096;
+  size_t perm_bytes = ((size_t)S.n_perlin * 768 + 15) & ~(size_t)15;
+  size_t info_bytes = pick_variant(S) < 2 ? (size_t)S.n_prims * sizeof(DPrimInfo) + (size_t)S.n_chains * sizeof(DChainRec) : 0;
+  return vec_bytes + perm_bytes + info_bytes + (size_t)block * (size_t)S.bvh_stack * 4;
+}
+
 template <class F>
-auto with_render_kernel(uint32_t features, bool count, F&& f) {
-  switch (pick_variant(features) * 2 + (count ? 1 : 0)) {
+auto with_render_kernel(const DScene& S, bool count, F&& f) {
+  switch (pick_variant(S) * 2 + (count ? 1 : 0)) {
     case 0: return f(k_render<V_RECT, false>);
     case 1: return f(k_render<V_RECT, true>);
     case 2: return f(k_render<V_SMOKE, false>);
@@ -306,7 +361,7 @@ auto with_render_kernel(uint32_t features, bool count, F&& f) {
 hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, float* out, uint32_t* queue,
                          unsigned long long* stats, bool count, int grid, hipStream_t stream) {
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
-  return with_render_kernel(S.features, count, [&](auto kernel) {
+  return with_render_kernel(S, count, [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(RT_BLOCK), lds, stream, S, cam, R, out, queue, stats);
     return hipGetLastError();
   });
@@ -314,7 +369,7 @@ hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, 
 
 hipError_t render_occupancy(const DScene& S, bool count, int* blocks_per_cu) {
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
-  return with_render_kernel(S.features, count, [&](auto kernel) {
+  return with_render_kernel(S, count, [&](auto kernel) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, RT_BLOCK, lds);
   });
 }
@@ -343,7 +398,7 @@ hipError_t launch_sample_batch(const DScene& S, const DCamera& cam, const DRende
                                const int* smp, float* out_rgb, hipStream_t stream) {
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
   dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
-  switch (pick_variant(S.features)) {  // the same instantiation the render would use
+  switch (pick_variant(S)) {  // the same instantiation the render would use
     case 0: hipLaunchKernelGGL(k_sample_batch<V_RECT>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     case 1: hipLaunchKernelGGL(k_sample_batch<V_SMOKE>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     default: hipLaunchKernelGGL(k_sample_batch<V_ALL>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;

@@ -20,6 +20,8 @@
 #define RT_BRUTE_MAX 16        // groups up to this size skip the BVH
 #define RT_MAX_PERLIN_LDS 8    // Perlin table sets staged in LDS
 #define RT_TILE 8              // pixels per tile edge; one wave64 = one 8x8 tile
+#define RT_RECT_STRIDE 5       // floats per record of DScene.brute_rects
+#define RT_RECT_BATCH 6        // rect records the brute-force loop fetches per scalar-memory round trip
 
 enum { DOP_TRANSLATE = 0, DOP_ROTATE_Y = 1 };
 
@@ -31,7 +33,8 @@ enum : uint32_t {
   F_CHAINS = 8,     // translate / rotate-y wrappers
   F_TEXTURES = 16,  // checker / noise / image textures
   F_SPECULAR = 32,  // metal / dielectric
-  F_ALL = 63
+  F_ALL = 63,
+  F_SMALL = 64      // not a scene feature: the instantiation keeps DPrimInfo in LDS (<= RT_LDS_PRIMS)
 };
 
 // 80 bytes. Spheres are intersected in FP64 (|oc|^2 - r^2 cancels catastrophically in FP32 for
@@ -55,6 +58,18 @@ struct DChain {
   int32_t first_op, n_ops;
 };
 
+// 80 bytes: a whole chain (FP32 side) in one record, so the record fix-ups on the way back up
+// need one lookup. Staged in LDS for small scenes.
+struct DChainRec {
+  int32_t n_ops;
+  int32_t pad[3];
+  struct Op {
+    int32_t kind;
+    float a, b, c;
+  } ops[RT_MAX_CHAIN_OPS];
+};
+#define RT_LDS_CHAINS 64  // F_SMALL instantiations keep up to this many chain records in LDS
+
 // 64 bytes, read with one scalar load by the brute-force loop. Primitives of a group are stored
 // by type (XY rects, XZ rects, YZ rects, spheres), stably, so each type gets a branch-free loop;
 // scan order within a type is kept, which preserves the reference's outcome for every tie
@@ -65,11 +80,12 @@ struct DGroup {
   int32_t bvh_root;  // node index, or -1 for the brute-force loops
   int32_t flags;     // DGROUP_*
   int32_t chain;
+  int32_t first_rect;  // first record of this group in DScene.brute_rects (brute-force groups)
   // The chain's ray transform collapsed to one rigid motion about y (translate.clj:11 and
   // rotate.clj:18-27 compose exactly): o' = Ry(o) + b, d' = Ry(d), Ry(v) = [c vx - s vz, vy, s vx + c vz].
   // Only the ray side may be collapsed; records go back up the chain operation by operation.
   float rc, rs, bx, by, bz;
-  int32_t pad[3];
+  int32_t pad[2];
 };
 struct DGroup64 {  // the same motion in FP64, for DGROUP_SPHERES_UNDER_CHAIN groups
   double rc, rs, bx, by, bz;
@@ -77,6 +93,22 @@ struct DGroup64 {  // the same motion in FP64, for DGROUP_SPHERES_UNDER_CHAIN gr
 };
 #define DGROUP_SPHERES_UNDER_CHAIN 1  // spheres below a non-identity chain: the ray is carried into
                                       // chain space in FP64 (as a float hi + lo pair)
+
+// 96 bytes: everything the winner of a traversal needs for its record and its scatter, gathered
+// so that the divergent (per-lane) lookup after the loops is ONE memory round trip. Staged in
+// LDS for small scenes.
+struct DPrimInfo {
+  int32_t type_group, mat, chain, gflags;  // as DPrim.type / DPrim.mat / DGroup.chain / DGroup.flags
+  float a0, a1, b0, b1;                    // rect bounds (for u, v)
+  float k, rc, rs, bx;                     // rect plane; the group's ray motion (DGroup)
+  float by, bz;
+  int32_t mtype, mflags;                   // DMat.type / DMat.flags of the material
+  int32_t mtex;
+  float r, g, b;                           // DMat.r g b
+  float x;                                 // DMat.x
+  int32_t pad[3];
+};
+#define RT_LDS_PRIMS 256  // scenes up to this many flattened primitives keep DPrimInfo in LDS
 
 struct DMedium {
   int32_t first_group, n_groups;  // boundary groups (indices into groups[])
@@ -120,9 +152,13 @@ struct DImage {
 
 struct DScene {
   const DPrim* prims;
+  const float* brute_rects;      // RT_RECT_STRIDE floats (a0 a1 b0 b1 k) per rect of every brute-force
+                                 // group, in group order, plus RT_RECT_BATCH records of slack
+  const DPrimInfo* prim_info;
   const DGroup* groups;
   const DGroup64* groups64;
   const DChain* chains;
+  const DChainRec* chain_recs;
   const DChainOp* ops;
   const DMedium* media;
   const DBvhNode* nodes;
@@ -135,7 +171,7 @@ struct DScene {
   int32_t n_surface_groups;      // groups [0, n_surface_groups) are tested for every ray
   int32_t n_groups;
   int32_t n_chains;
-  int32_t pad0;
+  int32_t n_prims;
   int32_t n_media;
   int32_t n_perlin;
   int32_t bvh_stack;             // entries per lane the traversal stack needs (0 = no BVH)

@@ -10,7 +10,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtmi.so")
+LIB_PATH = os.environ.get("RTMI_LIB", os.path.join(_HERE, "librtmi.so"))
 
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version", "rt_scene_create",
            "rt_scene_destroy", "rt_scene_get_info", "rt_render", "rt_render_device",
