@@ -177,7 +177,7 @@ def main():
             "flop_per_sample": flop_per_sample,
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "rt::k_render<false>", "kernel_ms": kern_ms_max,
+                         "kernel": "rt::k_render<FEAT, false> (the feature-specialised instantiation this scene selects)", "kernel_ms": kern_ms_max,
                          "note": "algorithmic FLOP per event x event counts of the counting build of the same "
                                  "kernel, per GPU, over that GPU's HIP-event kernel time; the path is branchy "
                                  "FP32 VALU work, neither HBM- nor MFMA-bound"},
