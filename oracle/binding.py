@@ -53,7 +53,7 @@ def lib():
         L.orc_sampler_scripted.argtypes = [C.c_int32, dp, C.c_int32, dp]
         L.orc_sampler_keyed.argtypes = [C.c_int32, C.c_uint64, C.c_int32, dp]
         L.orc_scatter_scripted.argtypes = [descp, C.c_int32, dp, dp, dp, C.c_int32, dp]
-        L.orc_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
+        L.orc_philox.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]
         L.orc_reflectance.argtypes = [C.c_double, C.c_double]
         L.orc_reflectance.restype = C.c_double
         L.orc_refract.argtypes = [dp, dp, C.c_double, dp]
@@ -173,9 +173,10 @@ def scatter_scripted(flat, mat, ray7, rec9, script):
                 emitted=out[11:14], used=used)
 
 
-def philox(ctr, key):
+def philox(ctr, key, rounds=0):
+    """Philox-4x32 with `rounds` rounds; 0 = the round count of the project's keyed stream."""
     c = (C.c_uint32 * 4)(*ctr)
     k = (C.c_uint32 * 2)(*key)
     o = (C.c_uint32 * 4)()
-    lib().orc_philox(c, k, o)
+    lib().orc_philox(c, k, rounds, o)
     return list(o)

@@ -21,7 +21,7 @@
 // implementation can follow. Draws here go through an Rng interface with two
 // back ends: Scripted (a caller-supplied sequence consumed in the reference's
 // evaluation order, for known-answer tests) and Keyed (counter-based
-// Philox-4x32-10 addressed by purpose, so the value of a draw does not depend on
+// Philox-4x32-7 addressed by purpose, so the value of a draw does not depend on
 // evaluation order and the device kernel can reproduce it).
 
 #include <algorithm>
@@ -77,11 +77,14 @@ struct HitRecord {  // base.clj:169
 };
 
 // ------------------------------------------------------------------ random source
-// Philox-4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11).
-inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+// Philox-4x32 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11). The keyed
+// stream of this project uses 7 rounds (kPhiloxRounds): the fewest for which the paper reports
+// the generator Crush-resistant (its default of 10 adds safety margin the renderer does not need).
+constexpr int kPhiloxRounds = 7;
+inline void philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds = kPhiloxRounds) {
   uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
   uint32_t k0 = key[0], k1 = key[1];
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < rounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -122,7 +125,7 @@ struct Rng {
   }
   void block(int purpose, int bounce, uint32_t blk, uint32_t out[4]) const {
     uint32_t ctr[4] = {blk, ((uint32_t)bounce << 4) | (uint32_t)purpose, seed_lo, seed_hi};
-    philox4x32_10(ctr, key, out);
+    philox4x32(ctr, key, out);
   }
   // (rand) (rand) at core.clj:99,101, then (random-double time0 time1)'s uniform at ray.clj:26.
   void camera(double& jx, double& jy) {
@@ -881,8 +884,8 @@ int orc_scatter_scripted(const rt_scene_desc* d, int32_t mat, const double* ray7
   out14[11] = em.x; out14[12] = em.y; out14[13] = em.z;
   return rng.script_overrun ? -1 : rng.script_pos;
 }
-void orc_philox(const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4) {
-  philox4x32_10(ctr4, key2, out4);
+void orc_philox(const uint32_t* ctr4, const uint32_t* key2, int rounds, uint32_t* out4) {
+  philox4x32(ctr4, key2, out4, rounds > 0 ? rounds : kPhiloxRounds);
 }
 double orc_reflectance(double cosine, double ref_idx) { return reflectance(cosine, ref_idx); }
 int orc_refract(const double* uv, const double* n, double eta, double* out3) {

@@ -283,7 +283,9 @@ bool tex_needs_uv(const rt_scene_desc* d, int tex, int depth = 0) {
   return false;
 }
 
-void fill_camera(const rt_camera* c, DCamera& o) {
+void fill_camera(const rt_camera* c, const rt_params* p, DCamera& o) {
+  o.wm1 = (double)(p->width - 1); o.hm1 = (double)(p->height - 1);
+  o.inv_wm1 = 1.0 / o.wm1; o.inv_hm1 = 1.0 / o.hm1;
   for (int a = 0; a < 3; ++a) {
     o.origin[a] = c->origin[a]; o.llc[a] = c->lower_left_corner[a];
     o.horizontal[a] = c->horizontal[a]; o.vertical[a] = c->vertical[a];
@@ -452,11 +454,28 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
         }
         prims.push_back(P);
       }
-      G.first_rect = (int)(brute_rects.size() / RT_RECT_STRIDE);
-      if ((int)list.size() <= RT_BRUTE_MAX)
-        for (size_t q = prims.size() - list.size(); q < prims.size(); ++q)
-          if ((prims[q].type & 15) >= RT_PRIM_XY_RECT)
-            for (int k = 0; k < RT_RECT_STRIDE; ++k) brute_rects.push_back(prims[q].f[k]);
+      G.first_rect = (int)(brute_rects.size() / RT_PAIR_STRIDE);
+      if ((int)list.size() <= RT_BRUTE_MAX) {
+        // pair records per orientation (see DScene.brute_rects)
+        int off = G.first_prim;
+        for (int n_t : {G.n_xy, G.n_xz, G.n_yz}) {
+          const int odd = n_t & 1;
+          for (int p = 0; p < (n_t + 1) / 2; ++p) {
+            const int i1 = off + 2 * p + 1 - odd;
+            const int i0 = std::max(i1 - 1, off);
+            const float* f0 = prims[(size_t)i0].f;
+            const float* f1 = prims[(size_t)i1].f;
+            // DPrim.f = a0 a1 b0 b1 k
+            for (int k : {4, 0, 1, 2, 3}) { brute_rects.push_back(f0[k]); brute_rects.push_back(f1[k]); }
+            float bits[2];
+            std::memcpy(&bits[0], &i0, 4);
+            std::memcpy(&bits[1], &i1, 4);
+            brute_rects.push_back(bits[0]);
+            brute_rects.push_back(bits[1]);
+          }
+          off += n_t;
+        }
+      }
       groups.push_back(G);
       groups64.push_back(H);
     }
@@ -627,7 +646,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   if (chains.size() > 1) features |= F_CHAINS;
   S.features = features;
 
-  brute_rects.resize(brute_rects.size() + RT_RECT_STRIDE * RT_RECT_BATCH, 0.f);  // slack for batched reads
+  brute_rects.resize(brute_rects.size() + RT_PAIR_STRIDE * RT_PAIR_BATCH, 0.f);  // slack for batched reads
   if ((rc = upload(sc, brute_rects, &S.brute_rects))) return rc;
   if ((rc = upload(sc, infos, &S.prim_info))) return rc;
   S.n_prims = (int)prims.size();
@@ -682,7 +701,7 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, cons
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   DCamera C;
-  fill_camera(cam, C);
+  fill_camera(cam, p, C);
   const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
   const size_t npix = (size_t)R.width * R.height;
   const size_t need = npix * 3 * sizeof(float) * (size_t)R.n_chunks;
@@ -794,7 +813,7 @@ int rt_sample_batch(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const
     if (px[i] < 0 || px[i] >= R.width * R.height || smp[i] < 0) return fail(RT_ERR_ARG, "sample %d: pixel or sample index out of range", i);
   HIPCHK(hipSetDevice(ctx->device));
   DCamera C;
-  fill_camera(cam, C);
+  fill_camera(cam, p, C);
   size_t bi = (size_t)n * sizeof(int32_t), bo = (size_t)n * 3 * sizeof(float);
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   rc = ensure_io(ctx, al(bi) * 2 + al(bo));

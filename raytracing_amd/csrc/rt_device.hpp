@@ -90,7 +90,9 @@ struct Tally<true> {
 };
 
 // ---------------------------------------------------------------------------------- RNG
-// Philox-4x32-10 (Salmon et al., SC'11). A draw is addressed, not sequenced:
+// Philox-4x32 (Salmon et al., SC'11) with 7 rounds, the fewest the paper reports Crush-resistant:
+// its 32x32->64 multiplies are the most expensive VALU instructions of the whole path loop. A draw
+// is addressed, not sequenced:
 //   key     = (pixel index y*W+x, global sample index)
 //   counter = (block, bounce << 4 | purpose, seed_lo, seed_hi)
 // so its value does not depend on evaluation order or on which GPU runs the sample.
@@ -98,6 +100,7 @@ struct Tally<true> {
 // representable in FP32 and FP64.
 enum { P_CAM = 0, P_DISK = 1, P_SPHERE = 2, P_DIEL = 3, P_MEDIUM = 4 };
 #define RT_MAX_TRIALS 256  // rejection loops give up here so every lane reaches the exit
+#define RT_PHILOX_ROUNDS 7
 
 struct Rng {
   uint32_t k0, k1, s0, s1;
@@ -107,7 +110,7 @@ RT_DEV void philox(const Rng& g, uint32_t blk, uint32_t bounce, uint32_t purpose
   uint32_t c0 = blk, c1 = (bounce << 4) | purpose, c2 = g.s0, c3 = g.s1;
   uint32_t k0 = g.k0, k1 = g.k1;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
     // one 32x32->64 multiply per word pair (v_mad_u64_u32)
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
@@ -403,34 +406,70 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
   }
 }
 
-// The rects of a brute-force group, stored by type (XY, XZ, YZ). RT_RECT_BATCH records are
-// fetched per trip with unconditional scalar loads (the table carries that much slack) and pinned
-// in SGPRs before any of them is used, so a box costs one scalar-memory round trip, not six.
+// Two rects of one orientation against the ray, in packed FP32 (one v_pk_* instruction serves
+// both). rectangles.clj:20-30 / :57-67 / :94-104: t from the constant axis, then reject iff
+// t < t-min, t > t-max, or the in-plane point lies outside [a0,a1] x [b0,b1] — all six bounds are
+// accepted inclusively, so each of the six differences below is >= 0 (sign bit clear) exactly when
+// its comparison accepts; x - x is +0, so equality accepts, and a later rect wins an exact tie
+// with the closest-so-far. OR-ing the six sign bits replaces six compares. Slot 0 is tested before
+// slot 1 against the closest-so-far, as the reference's scan would.
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int TYPE>
+RT_DEV void rect_pair(f2 k, f2 a0, f2 a1, f2 b0, f2 b1, int i0, int i1, const RayX& r, float tmin, Best& best) {
+  float oc, ic, oa, da, ob, db;
+  if (TYPE == RT_PRIM_XY_RECT) { oc = r.o.z; ic = r.inv.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
+  else if (TYPE == RT_PRIM_XZ_RECT) { oc = r.o.y; ic = r.inv.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
+  else { oc = r.o.x; ic = r.inv.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
+  const f2 t = (k - (f2){oc, oc}) * (f2){ic, ic};
+  const f2 a = __builtin_elementwise_fma(t, (f2){da, da}, (f2){oa, oa});
+  const f2 b = __builtin_elementwise_fma(t, (f2){db, db}, (f2){ob, ob});
+  const f2 e1 = a - a0, e2 = a1 - a, e3 = b - b0, e4 = b1 - b, e5 = t - (f2){tmin, tmin};
+  {
+    const float e6 = best.t - t.x;
+    const int s = __float_as_int(e1.x) | __float_as_int(e2.x) | __float_as_int(e3.x) | __float_as_int(e4.x) |
+                  __float_as_int(e5.x) | __float_as_int(e6);
+    const bool ok = s >= 0;
+    best.t = ok ? t.x : best.t;
+    best.prim = ok ? i0 : best.prim;
+  }
+  {
+    const float e6 = best.t - t.y;
+    const int s = __float_as_int(e1.y) | __float_as_int(e2.y) | __float_as_int(e3.y) | __float_as_int(e4.y) |
+                  __float_as_int(e5.y) | __float_as_int(e6);
+    const bool ok = s >= 0;
+    best.t = ok ? t.y : best.t;
+    best.prim = ok ? i1 : best.prim;
+  }
+}
+
+// The rects of a brute-force group as pair records (DScene.brute_rects), XY pairs first, then XZ,
+// then YZ. RT_PAIR_BATCH records are fetched per trip with unconditional scalar loads (the table
+// carries that much slack) and pinned in SGPRs before any of them is used, so a box costs one
+// scalar-memory round trip.
 template <class T>
-RT_DEV void brute_rects(const float RT_CONST* R, int first_prim, int n_xy, int n_xz, int n_yz, const RayX& r,
-                        float tmin, Best& best, T& tally) {
-  const int n = n_xy + n_xz + n_yz;
-  for (int base = 0; base < n; base += RT_RECT_BATCH) {
-    float v[RT_RECT_BATCH * RT_RECT_STRIDE];
+RT_DEV void brute_rects(const float RT_CONST* R, int n_xy, int n_xz, int n_yz, const RayX& r, float tmin, Best& best,
+                        T& tally) {
+  const int p_xy = (n_xy + 1) >> 1, p_xz = p_xy + ((n_xz + 1) >> 1), np = p_xz + ((n_yz + 1) >> 1);
+  for (int base = 0; base < np; base += RT_PAIR_BATCH) {
+    float v[RT_PAIR_BATCH * RT_PAIR_STRIDE];
 #pragma unroll
-    for (int q = 0; q < RT_RECT_BATCH * RT_RECT_STRIDE; ++q) v[q] = R[base * RT_RECT_STRIDE + q];
+    for (int q = 0; q < RT_PAIR_BATCH * RT_PAIR_STRIDE; ++q) v[q] = R[base * RT_PAIR_STRIDE + q];
     asm volatile("" ::"s"(v[0]), "s"(v[1]), "s"(v[2]), "s"(v[3]), "s"(v[4]), "s"(v[5]), "s"(v[6]), "s"(v[7]), "s"(v[8]),
                  "s"(v[9]), "s"(v[10]), "s"(v[11]), "s"(v[12]), "s"(v[13]), "s"(v[14]), "s"(v[15]), "s"(v[16]),
                  "s"(v[17]), "s"(v[18]), "s"(v[19]), "s"(v[20]), "s"(v[21]), "s"(v[22]), "s"(v[23]), "s"(v[24]),
-                 "s"(v[25]), "s"(v[26]), "s"(v[27]), "s"(v[28]), "s"(v[29]));
+                 "s"(v[25]), "s"(v[26]), "s"(v[27]), "s"(v[28]), "s"(v[29]), "s"(v[30]), "s"(v[31]), "s"(v[32]),
+                 "s"(v[33]), "s"(v[34]), "s"(v[35]));
 #pragma unroll
-    for (int j = 0; j < RT_RECT_BATCH; ++j) {
-      const int idx = base + j;
-      if (idx < n) {  // wave-uniform, as is the type of the record
-        const float* w = v + j * RT_RECT_STRIDE;
-        float t;
-        bool ok;
-        tally.template add<RT_EV_RECT_TEST>();
-        if (idx < n_xy) ok = rect_ok<RT_PRIM_XY_RECT>(w[0], w[1], w[2], w[3], w[4], r, tmin, best.t, t);
-        else if (idx < n_xy + n_xz) ok = rect_ok<RT_PRIM_XZ_RECT>(w[0], w[1], w[2], w[3], w[4], r, tmin, best.t, t);
-        else ok = rect_ok<RT_PRIM_YZ_RECT>(w[0], w[1], w[2], w[3], w[4], r, tmin, best.t, t);
-        best.t = ok ? t : best.t;
-        best.prim = ok ? first_prim + idx : best.prim;
+    for (int j = 0; j < RT_PAIR_BATCH; ++j) {
+      const int q = base + j;
+      if (q < np) {  // wave-uniform, as is the orientation of the pair
+        const float* w = v + j * RT_PAIR_STRIDE;
+        const f2 k = {w[0], w[1]}, a0 = {w[2], w[3]}, a1 = {w[4], w[5]}, b0 = {w[6], w[7]}, b1 = {w[8], w[9]};
+        const int i0 = __float_as_int(w[10]), i1 = __float_as_int(w[11]);
+        tally.template add<RT_EV_RECT_TEST>(i0 == i1 ? 1 : 2);
+        if (q < p_xy) rect_pair<RT_PRIM_XY_RECT>(k, a0, a1, b0, b1, i0, i1, r, tmin, best);
+        else if (q < p_xz) rect_pair<RT_PRIM_XZ_RECT>(k, a0, a1, b0, b1, i0, i1, r, tmin, best);
+        else rect_pair<RT_PRIM_YZ_RECT>(k, a0, a1, b0, b1, i0, i1, r, tmin, best);
       }
     }
   }
@@ -449,7 +488,7 @@ RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best
     const DPrim RT_CONST* prims = cptr(S.prims);
     int first = G.first_prim;
     const int n_xy = G.n_xy, n_xz = G.n_xz, n_yz = G.n_yz;
-    brute_rects(cptr(S.brute_rects) + G.first_rect * RT_RECT_STRIDE, first, n_xy, n_xz, n_yz, r, tmin, best, tally);
+    brute_rects(cptr(S.brute_rects) + G.first_rect * RT_PAIR_STRIDE, n_xy, n_xz, n_yz, r, tmin, best, tally);
     first += n_xy + n_xz + n_yz;
     if constexpr (X::has(F_SPHERES)) {
       const int n_sph = G.n_sph;
@@ -889,13 +928,24 @@ RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t
 
 // --------------------------------------------------------------------------------- camera
 // core.clj:96-102 + ray.clj:14-26 in FP64 (once per path), rounded to the FP32 path state.
-template <class T>
-RT_DEV Ray camera_ray(const DCamera& cam, const DRender& R, int x, int y, const Rng& g, T& tally) {
+// n / d in FP64, correctly rounded, given r = RN(1/d) (Markstein): q = RN(n r), then one FMA
+// residual and one FMA correction. Three instructions instead of the ~12 of a full division;
+// d = 0 (a one-pixel-wide image) takes the real division and its IEEE result.
+RT_DEV double exact_div(double n, double d, double r) {
+  if (d == 0.0) return n / d;
+  double q = n * r;
+  return fma(fma(-q, d, n), r, q);
+}
+
+// `camp` points at a DCamera in any address space (the kernarg segment for the render kernel).
+template <class CAMP, class T>
+RT_DEV Ray camera_ray(CAMP camp, int x, int y, const Rng& g, T& tally) {
+  const auto& cam = *camp;
   tally.template add<RT_EV_CAMERA_RAY>();
   uint32_t o4[4];
   philox(g, 0, 0, P_CAM, o4);
-  double s = ((double)x + (double)u24(o4[0])) / (double)(R.width - 1);
-  double t = ((double)y + (double)u24(o4[1])) / (double)(R.height - 1);
+  double s = exact_div((double)x + (double)u24(o4[0]), cam.wm1, cam.inv_wm1);
+  double t = exact_div((double)y + (double)u24(o4[1]), cam.hm1, cam.inv_hm1);
   double time_ = fma(cam.time1 - cam.time0, (double)u24(o4[2]), cam.time0);
   // random-in-unit-disk (base.clj:188-194): draw 0 never tested, first later draw inside the disk.
   // The reference draws it even when the lens radius is 0 (ray.clj:18); the result is then

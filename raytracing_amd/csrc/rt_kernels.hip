@@ -114,18 +114,37 @@ constexpr int waves_per_simd(uint32_t feat, bool count) {
   return (feat & (F_SPHERES | F_BVH | F_TEXTURES)) ? 2 : (count ? 4 : RT_WAVES_LEAN);
 }
 
+// All arguments of k_render in one struct, so that its layout IS the kernarg segment's. Fields the
+// loop needs rarely (the camera's 21 doubles, the queue geometry) are not kept in SGPRs across the
+// traversal loops, where they would be spilled into VGPR lanes and read back with VALU
+// instructions; they are re-read from the kernarg segment (scalar loads, scalar cache) at the point
+// of use, through a pointer the optimiser cannot see through (see `cold()`).
+struct RenderArgs {
+  DScene S;
+  DCamera cam;
+  DRender R;
+  float* out;
+  uint32_t* queue;
+  unsigned long long* stats;
+};
+__device__ __forceinline__ const RenderArgs RT_CONST* cold() {
+  const RenderArgs RT_CONST* p = (const RenderArgs RT_CONST*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));  // opaque: loads through p are neither hoisted out of the loop nor merged
+  return p;
+}
+
 template <uint32_t FEAT, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_render(DScene S, DCamera cam, DRender R, float* __restrict__ out,
-                                                     uint32_t* __restrict__ queue,
-                                                     unsigned long long* __restrict__ stats) {
+__global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_render(RenderArgs A) {
   extern __shared__ __align__(16) unsigned char lds[];
-  Ctx<FEAT> X = make_ctx<FEAT>(S, lds);
+  Ctx<FEAT> X = make_ctx<FEAT>(A.S, lds);
+  const DRender& R = A.R;
+  float* __restrict__ out = A.out;
+  unsigned long long* __restrict__ stats = A.stats;
   Tally<COUNT> tally;
   if constexpr (COUNT) tally.clear();
 
   const uint32_t lane = threadIdx.x & 63u;
   const int npix = R.width * R.height;
-  const int items_per_chunk = R.n_owned_tiles * 64;
 
   // wave-uniform queue window [q_next, q_end) of work items taken from the global queue
   uint32_t q_next = 0, q_end = 0;
@@ -156,15 +175,17 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
     }
     unsigned long long mask = __ballot(need);
     if (mask != 0ull) {  // wave-uniform
+      const RenderArgs RT_CONST* C = cold();
+      const uint32_t batch = (uint32_t)C->R.batch, n_items = (uint32_t)C->R.n_items;
       if (q_next == q_end && !q_dry) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(queue, (uint32_t)R.batch);
+        if (lane == 0) base = atomicAdd(C->queue, batch);
         base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= (uint32_t)R.n_items) {
+        if (base >= n_items) {
           q_dry = true;
         } else {
           q_next = base;
-          q_end = min(base + (uint32_t)R.batch, (uint32_t)R.n_items);
+          q_end = min(base + batch, n_items);
         }
       }
       uint32_t avail = q_end - q_next;
@@ -172,17 +193,19 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       if (need) {
         uint32_t rank = lane_rank(mask);
         if (rank < avail) {
+          const uint32_t items_per_chunk = (uint32_t)C->R.n_owned_tiles * 64u;
+          const int tiles_x = C->R.tiles_x, width = C->R.width, height = C->R.height;
           uint32_t item = q_next + rank;
-          chunk_id = (int)(item / (uint32_t)items_per_chunk);
-          uint32_t rem = item - (uint32_t)chunk_id * (uint32_t)items_per_chunk;
-          int tile = R.shard_index + (int)(rem >> 6) * R.shard_count;
+          chunk_id = (int)(item / items_per_chunk);
+          uint32_t rem = item - (uint32_t)chunk_id * items_per_chunk;
+          int tile = C->R.shard_index + (int)(rem >> 6) * C->R.shard_count;
           int in_tile = (int)(rem & 63u);
-          px = (tile % R.tiles_x) * RT_TILE + (in_tile & 7);
-          py = (tile / R.tiles_x) * RT_TILE + (in_tile >> 3);
-          if (px < R.width && py < R.height) {
-            pix = py * R.width + px;
-            s = chunk_id * R.chunk;
-            s_end = min(R.spp, s + R.chunk);
+          px = (tile % tiles_x) * RT_TILE + (in_tile & 7);
+          py = (tile / tiles_x) * RT_TILE + (in_tile >> 3);
+          if (px < width && py < height) {
+            pix = py * width + px;
+            s = chunk_id * C->R.chunk;
+            s_end = min(C->R.spp, s + C->R.chunk);
             acc = mk(0.f, 0.f, 0.f);
             have_item = true;
           }
@@ -202,7 +225,10 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       if (R.max_depth <= 0) {
         tally.template add<RT_EV_ACCUMULATE>();
       } else {
-        ray = camera_ray(cam, R, px, py, g, tally);
+        {
+          const RenderArgs RT_CONST* C = cold();
+          ray = camera_ray(&C->cam, px, py, g, tally);
+        }
         beta = mk(1.f, 1.f, 1.f);
         bounce = 0;
         active = true;
@@ -313,7 +339,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_sample_batch(DScene S, DCamera cam
   Rng g{(uint32_t)px[i], (uint32_t)smp[i], R.seed_lo, R.seed_hi};
   V3 L = mk(0.f, 0.f, 0.f);
   if (R.max_depth > 0) {
-    Ray ray = camera_ray(cam, R, px[i] % R.width, px[i] / R.width, g, tally);
+    Ray ray = camera_ray(&cam, px[i] % R.width, px[i] / R.width, g, tally);
     V3 beta = mk(1.f, 1.f, 1.f);
     uint32_t bounce = 0;
     while (!path_step(X, R, ray, beta, bounce, g, L, tally)) {}
@@ -362,7 +388,9 @@ hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, 
                          unsigned long long* stats, bool count, int grid, hipStream_t stream) {
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
   return with_render_kernel(S, count, [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(RT_BLOCK), lds, stream, S, cam, R, out, queue, stats);
+    RenderArgs A;
+    A.S = S; A.cam = cam; A.R = R; A.out = out; A.queue = queue; A.stats = stats;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(RT_BLOCK), lds, stream, A);
     return hipGetLastError();
   });
 }

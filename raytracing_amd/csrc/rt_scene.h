@@ -20,8 +20,8 @@
 #define RT_BRUTE_MAX 16        // groups up to this size skip the BVH
 #define RT_MAX_PERLIN_LDS 8    // Perlin table sets staged in LDS
 #define RT_TILE 8              // pixels per tile edge; one wave64 = one 8x8 tile
-#define RT_RECT_STRIDE 5       // floats per record of DScene.brute_rects
-#define RT_RECT_BATCH 6        // rect records the brute-force loop fetches per scalar-memory round trip
+#define RT_PAIR_STRIDE 12      // dwords per pair record of DScene.brute_rects
+#define RT_PAIR_BATCH 3        // pair records the brute-force loop fetches per scalar-memory round trip
 
 enum { DOP_TRANSLATE = 0, DOP_ROTATE_Y = 1 };
 
@@ -80,7 +80,7 @@ struct DGroup {
   int32_t bvh_root;  // node index, or -1 for the brute-force loops
   int32_t flags;     // DGROUP_*
   int32_t chain;
-  int32_t first_rect;  // first record of this group in DScene.brute_rects (brute-force groups)
+  int32_t first_rect;  // first pair record of this group in DScene.brute_rects (brute-force groups)
   // The chain's ray transform collapsed to one rigid motion about y (translate.clj:11 and
   // rotate.clj:18-27 compose exactly): o' = Ry(o) + b, d' = Ry(d), Ry(v) = [c vx - s vz, vy, s vx + c vz].
   // Only the ray side may be collapsed; records go back up the chain operation by operation.
@@ -152,8 +152,12 @@ struct DImage {
 
 struct DScene {
   const DPrim* prims;
-  const float* brute_rects;      // RT_RECT_STRIDE floats (a0 a1 b0 b1 k) per rect of every brute-force
-                                 // group, in group order, plus RT_RECT_BATCH records of slack
+  const float* brute_rects;      // the rects of every brute-force group as PAIRS of one orientation, so one
+                                 // packed-FP32 instruction serves two rects: k k' a0 a0' a1 a1' b0 b0' b1 b1'
+                                 // then the two device primitive indices (int bits). Per group: XY pairs, XZ
+                                 // pairs, YZ pairs. A run of odd length starts with a pair whose first slot
+                                 // repeats its second (same index): the repeat is tested first and the real
+                                 // rect, accepting a tie, overwrites it. RT_PAIR_BATCH records of slack follow.
   const DPrimInfo* prim_info;
   const DGroup* groups;
   const DGroup64* groups64;
@@ -181,6 +185,9 @@ struct DScene {
 struct DCamera {  // the reference's camera map in FP64 (camera.clj:24-33)
   double origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3];
   double lens_radius, time0, time1;
+  // core.clj:99,101 divide the jittered pixel coordinate by W-1 and H-1: the divisors and their
+  // correctly rounded reciprocals, for an exact division in three FMAs (see camera_ray)
+  double wm1, hm1, inv_wm1, inv_hm1;
 };
 
 struct DRender {

@@ -365,11 +365,16 @@ def test_camera_map(oracle):  # camera.clj:7-33 with core.clj:75-79,89-91 (Corne
 
 
 def test_philox_known_answers(oracle):
-    # Random123 kat_vectors: philox4x32-10
-    assert oracle.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
-    assert oracle.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
-    assert oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
-        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    pi_ctr, pi_key = [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]
+    # Random123 kat_vectors: philox4x32 with 10 rounds (the library default) ...
+    assert oracle.philox([0, 0, 0, 0], [0, 0], 10) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox([0xffffffff] * 4, [0xffffffff] * 2, 10) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox(pi_ctr, pi_key, 10) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # ... and with 7 rounds, the count the keyed stream of this project uses
+    assert oracle.philox([0, 0, 0, 0], [0, 0], 7) == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    assert oracle.philox([0xffffffff] * 4, [0xffffffff] * 2, 7) == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
+    assert oracle.philox(pi_ctr, pi_key, 7) == [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]
+    assert oracle.philox(pi_ctr, pi_key) == oracle.philox(pi_ctr, pi_key, 7)
 
 
 def test_ray_color_depth_and_background(oracle):  # core.clj:19-30

@@ -32,7 +32,7 @@ def probe_rays(cfg, n, seed):
 
 def medium_uniform(seed, px, smp, bounce, m):
     """The keyed uniform of medium m at ray-color invocation `bounce` (same addressing as the
-    device and the oracle): Philox-4x32-10, counter (m>>2, bounce<<4|4, seed), key (px, smp)."""
+    device and the oracle): Philox-4x32-7, counter (m>>2, bounce<<4|4, seed), key (px, smp)."""
     from oracle import binding as ob
     o = ob.philox([m >> 2, (bounce << 4) | 4, seed & 0xFFFFFFFF, seed >> 32], [px, smp])
     return (o[m & 3] >> 8) / 16777216.0
