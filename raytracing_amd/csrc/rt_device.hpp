@@ -361,6 +361,14 @@ RT_DEV bool slab(const float* mn, const float* mx, const RayX& r, float tmin, fl
   return tn <= tf;
 }
 
+// Closest hit below BVH node `root`. Two nested loops: a lane walks internal nodes (near child
+// first, far child on its LDS stack) until it HOLDS a leaf, and only when every lane of the wave
+// holds a leaf or has finished are the leaves intersected, together. Testing a leaf where it is
+// met would make every step of the walk pay for a primitive test that a few lanes need.
+// A node reference is >= 0 for an internal node, ~primitive for a leaf, RT_BVH_DONE when the lane
+// has nothing left. Leaves are visited out of scan order: test_prim_any_order applies the
+// reference's tie rule explicitly.
+#define RT_BVH_DONE 0x7fffffff
 template <class X, class T>
 RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best& best, T& tally) {
   const DScene& S = ctx.S;
@@ -368,40 +376,41 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
   const f4 RT_CONST* nodes4 = reinterpret_cast<const f4 RT_CONST*>(cptr(S.nodes));
   int sp = 0;
   int node = root;
-  for (;;) {
-    const f4 q0 = nodes4[node * 4 + 0];
-    const f4 q1 = nodes4[node * 4 + 1];
-    const f4 q2 = nodes4[node * 4 + 2];
-    const f4 q3 = nodes4[node * 4 + 3];
-    const float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
-    const float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
-    int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-    float tl, tr;
-    tally.template add<RT_EV_AABB_TEST>(2);
-    bool hl = slab(lmin, lmax, r, tmin, best.t, tl);
-    bool hr = slab(rmin, rmax, r, tmin, best.t, tr);
-    // leaves are tested on the spot; internal children are visited near child first
-    if (hl && left < 0) { test_prim_any_order<X>(S, ~left, r, tmin, best, tally); hl = false; }
-    if (hr && right < 0) {
-      if (tr <= best.t) test_prim_any_order<X>(S, ~right, r, tmin, best, tally);
-      hr = false;
+  while (node != RT_BVH_DONE) {
+    while ((unsigned)node < (unsigned)RT_BVH_DONE) {  // internal
+      const f4 q0 = nodes4[node * 4 + 0];
+      const f4 q1 = nodes4[node * 4 + 1];
+      const f4 q2 = nodes4[node * 4 + 2];
+      const f4 q3 = nodes4[node * 4 + 3];
+      const float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
+      const float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
+      const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+      float tl, tr;
+      tally.template add<RT_EV_AABB_TEST>(2);
+      const bool hl = slab(lmin, lmax, r, tmin, best.t, tl);
+      const bool hr = slab(rmin, rmax, r, tmin, best.t, tr);
+      if (hl && hr) {
+        const bool swap = tr < tl;
+        ctx.lds_stack[sp * ctx.stack_stride] = swap ? left : right;
+        ++sp;
+        node = swap ? right : left;
+      } else if (hl || hr) {
+        node = hl ? left : right;
+      } else if (sp > 0) {
+        --sp;
+        node = ctx.lds_stack[sp * ctx.stack_stride];
+      } else {
+        node = RT_BVH_DONE;
+      }
     }
-    if (hl && tl > best.t) hl = false;
-    if (hr && tr > best.t) hr = false;
-    if (hl && hr) {
-      int near = left, far = right;
-      if (tr < tl) { near = right; far = left; }
-      ctx.lds_stack[sp * ctx.stack_stride] = far;
-      ++sp;
-      node = near;
-    } else if (hl) {
-      node = left;
-    } else if (hr) {
-      node = right;
-    } else {
-      if (sp == 0) break;
-      --sp;
-      node = ctx.lds_stack[sp * ctx.stack_stride];
+    if (node != RT_BVH_DONE) {  // a leaf
+      test_prim_any_order<X>(S, ~node, r, tmin, best, tally);
+      if (sp > 0) {
+        --sp;
+        node = ctx.lds_stack[sp * ctx.stack_stride];
+      } else {
+        node = RT_BVH_DONE;
+      }
     }
   }
 }
