@@ -545,6 +545,9 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
     if (M.type == RT_MAT_ISOTROPIC) features |= F_MEDIA;
     mats[i] = M;
   }
+  if (features & F_TEXTURES)
+    for (int i = 0; i < d->n_tex; ++i)
+      features |= d->tex_type[i] == RT_TEX_NOISE ? F_NOISE : d->tex_type[i] == RT_TEX_IMAGE ? F_IMAGE : 0u;
   std::vector<DTex> texs((size_t)d->n_tex);
   for (int i = 0; i < d->n_tex; ++i) {
     DTex T;

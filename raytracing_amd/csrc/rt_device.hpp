@@ -207,23 +207,15 @@ RT_DEV D3 rayx_d64(const RayX& r) { return mkd((double)r.d.x + (double)r.d_lo.x,
 // t < t-min or t > t-max (so equality with the closest-so-far is accepted and a later rect
 // wins an exact tie), then the inclusive in-plane bounds. Written without branches: the six
 // comparisons keep the reference's polarity (a NaN passes them, as it does there).
-template <int TYPE>
-RT_DEV bool rect_ok(float a0, float a1, float b0, float b1, float k, const RayX& r, float tmin, float tmax, float& t) {
-  float oc, ic, oa, da, ob, db;
-  if (TYPE == RT_PRIM_XY_RECT) { oc = r.o.z; ic = r.inv.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
-  else if (TYPE == RT_PRIM_XZ_RECT) { oc = r.o.y; ic = r.inv.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
-  else { oc = r.o.x; ic = r.inv.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
+RT_DEV bool rect_ok_axes(float a0, float a1, float b0, float b1, float k, float oc, float ic, float oa, float da,
+                         float ob, float db, float tmin, float tmax, float& t) {
   t = (k - oc) * ic;
   float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
-#ifdef RT_RECT_CMP_CHAIN
-  return !(t < tmin) & !(t > tmax) & !(a < a0) & !(a > a1) & !(b < b0) & !(b > b1);
-#else
   // One signed "outside distance" instead of six compares chained through scalar masks: each of
   // the six terms is > 0 exactly when the reference's rejecting comparison holds; fmaxf drops a
   // NaN term, as the reference's comparisons let a NaN pass.
   float m = fmaxf(fmaxf(fmaxf(a0 - a, a - a1), fmaxf(b0 - b, b - b1)), fmaxf(tmin - t, t - tmax));
   return !(m > 0.0f);
-#endif
 }
 
 template <class PRIM>
@@ -291,10 +283,16 @@ RT_DEV void test_prim_any_order(const DScene& S, int idx, const RayX& r, float t
   bool second = false;
   if (is_rect(type)) {
     tally.template add<RT_EV_RECT_TEST>();
-    bool ok;
-    if (type == RT_PRIM_XY_RECT) ok = rect_ok<RT_PRIM_XY_RECT>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
-    else if (type == RT_PRIM_XZ_RECT) ok = rect_ok<RT_PRIM_XZ_RECT>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
-    else ok = rect_ok<RT_PRIM_YZ_RECT>(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], r, tmin, best.t, t);
+    // The orientation differs per lane here: select the ray's components. The copies are made
+    // opaque first; selecting between loads of one struct would otherwise be rewritten into a
+    // load from a selected address, which parks the whole ray in scratch memory.
+    float ox = r.o.x, oy = r.o.y, oz = r.o.z, dx = r.d.x, dy = r.d.y, dz = r.d.z, ix = r.inv.x, iy = r.inv.y, iz = r.inv.z;
+    asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz), "+v"(dx), "+v"(dy), "+v"(dz), "+v"(ix), "+v"(iy), "+v"(iz));
+    const bool xy = type == RT_PRIM_XY_RECT, xz = type == RT_PRIM_XZ_RECT;
+    const float oc = xy ? oz : (xz ? oy : ox), ic = xy ? iz : (xz ? iy : ix);
+    const float oa = (xy | xz) ? ox : oy, da = (xy | xz) ? dx : dy;
+    const float ob = xy ? oy : oz, db = xy ? dy : dz;
+    const bool ok = rect_ok_axes(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], oc, ic, oa, da, ob, db, tmin, best.t, t);
     if (!ok) return;
     if (t == best.t && best.prim >= 0) {
       int bi = best.prim & ~RT_SECOND_ROOT;
@@ -724,7 +722,7 @@ RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, con
     const DPrimInfo I = load_info(ctx, prim);
     RayX rx = group_ray<X>(S, prim_group(I.type_group), I.gflags, I.rc, I.rs, I.bx, I.by, I.bz, wr, tally);
     bool want_uv = want_uv_always;
-    if constexpr (X::has(F_TEXTURES)) want_uv = want_uv || (I.mflags & DMAT_NEEDS_UV) != 0;
+    if constexpr (X::has(F_IMAGE)) want_uv = want_uv || (I.mflags & DMAT_NEEDS_UV) != 0;
     prim_record<X>(S, prim, I, rx, best.t, second_root, want_uv, rec, tally);
     chain_unwind(ctx, I.chain, wr.d, rec, tally);
   } else {
@@ -823,12 +821,14 @@ RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, T& tally)
     type = texs[tex].type;
   }
   if (type == RT_TEX_SOLID) return mk(texs[tex].r, texs[tex].g, texs[tex].b);  // :15-17
-  if (type == RT_TEX_NOISE) {                                                  // :41-44
-    tally.template add<RT_EV_NOISE_TEX>();
-    float k = 0.5f * (1.0f + sinf(fmaf((float)texs[tex].i1, p.z, 10.0f * perlin_turb(ctx, texs[tex].i0, p, 7, tally))));
-    return mk(k, k, k);
+  if constexpr (X::has(F_NOISE)) {
+    if (type == RT_TEX_NOISE) {  // :41-44
+      tally.template add<RT_EV_NOISE_TEX>();
+      float k = 0.5f * (1.0f + sinf(fmaf((float)texs[tex].i1, p.z, 10.0f * perlin_turb(ctx, texs[tex].i0, p, 7, tally))));
+      return mk(k, k, k);
+    }
   }
-  if (type == RT_TEX_IMAGE) {  // :55-66
+  if (X::has(F_IMAGE) && type == RT_TEX_IMAGE) {  // :55-66
     tally.template add<RT_EV_IMAGE_TEX>();
     const int img = texs[tex].i0;
     if (img < 0) return mk(0.f, 1.f, 1.f);

@@ -36,7 +36,7 @@ __device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* ld
   uint8_t* lp = lds + vec_bytes;
   const float4* gv = reinterpret_cast<const float4*>(S.perlin_vec);
   size_t info_bytes = 0;
-  if constexpr ((FEAT & F_TEXTURES) != 0) {
+  if constexpr ((FEAT & F_NOISE) != 0) {
     for (int i = threadIdx.x; i < S.n_perlin * 256; i += blockDim.x) lv[i] = gv[i];
     for (int i = threadIdx.x; i < S.n_perlin * 768; i += blockDim.x) lp[i] = S.perlin_perm[i];
   }
@@ -55,7 +55,7 @@ __device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* ld
     X.lds_info = (const DPrimInfo RT_LDS*)(lds + vec_bytes + perm_bytes);
     X.lds_chains = (const DChainRec RT_LDS*)(lds + vec_bytes + perm_bytes + pi_bytes);
   }
-  if constexpr ((FEAT & (F_TEXTURES | F_SMALL)) != 0) __syncthreads();
+  if constexpr ((FEAT & (F_NOISE | F_SMALL)) != 0) __syncthreads();
   X.lds_perlin_vec = reinterpret_cast<const float*>(lv);
   X.lds_perlin_perm = lp;
   X.lds_stack = reinterpret_cast<int*>(lds + vec_bytes + perm_bytes + info_bytes) + threadIdx.x;
@@ -111,7 +111,9 @@ __device__ __forceinline__ bool path_step(const XC& X, const DRender& R, Ray& ra
 // the whole file): the lean instantiations are latency-bound on scalar loads and the RNG's
 // integer multiplies, which more resident waves hide.
 constexpr int waves_per_simd(uint32_t feat, bool count) {
-  return (feat & (F_SPHERES | F_BVH | F_TEXTURES)) ? 2 : (count ? 4 : RT_WAVES_LEAN);
+  if (feat & F_NOISE) return 2;
+  if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : 4;
+  return count ? 4 : RT_WAVES_LEAN;
 }
 
 // All arguments of k_render in one struct, so that its layout IS the kernarg segment's. Fields the
@@ -353,16 +355,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_sample_batch(DScene S, DCamera cam
 //   V_RECT   axis-aligned rects under translate/rotate-y chains, solid-colour Lambertians and lights
 //            (the Cornell box)
 //   V_SMOKE  + constant media with isotropic phase functions (the Cornell smoke box)
+//   V_SPH    spheres and rects at the top level, BVHs, metal / dielectric, checker and image
+//            textures: everything of the first book (the random-spheres world, the earth)
 //   V_ALL    everything
 constexpr uint32_t V_RECT = F_CHAINS | F_SMALL;
 constexpr uint32_t V_SMOKE = F_CHAINS | F_MEDIA | F_SMALL;
+constexpr uint32_t V_SPH = F_SPHERES | F_BVH | F_SPECULAR | F_TEXTURES;
 constexpr uint32_t V_ALL = F_ALL;
 
 int pick_variant(const DScene& S) {
   const bool small = S.n_prims <= RT_LDS_PRIMS && S.n_chains <= RT_LDS_CHAINS;
   if (small && (S.features & ~V_RECT) == 0) return 0;
   if (small && (S.features & ~V_SMOKE) == 0) return 1;
-  return 2;
+  if ((S.features & ~V_SPH) == 0) return 2;
+  return 3;
 }
 
 size_t shade_lds_bytes(const DScene& S, int block) {
@@ -379,7 +385,9 @@ auto with_render_kernel(const DScene& S, bool count, F&& f) {
     case 1: return f(k_render<V_RECT, true>);
     case 2: return f(k_render<V_SMOKE, false>);
     case 3: return f(k_render<V_SMOKE, true>);
-    case 4: return f(k_render<V_ALL, false>);
+    case 4: return f(k_render<V_SPH, false>);
+    case 5: return f(k_render<V_SPH, true>);
+    case 6: return f(k_render<V_ALL, false>);
     default: return f(k_render<V_ALL, true>);
   }
 }
@@ -429,6 +437,7 @@ hipError_t launch_sample_batch(const DScene& S, const DCamera& cam, const DRende
   switch (pick_variant(S)) {  // the same instantiation the render would use
     case 0: hipLaunchKernelGGL(k_sample_batch<V_RECT>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     case 1: hipLaunchKernelGGL(k_sample_batch<V_SMOKE>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
+    case 2: hipLaunchKernelGGL(k_sample_batch<V_SPH>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     default: hipLaunchKernelGGL(k_sample_batch<V_ALL>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
   }
   return hipGetLastError();

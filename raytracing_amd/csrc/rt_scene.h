@@ -31,10 +31,12 @@ enum : uint32_t {
   F_BVH = 2,        // at least one group is traversed through a BVH
   F_MEDIA = 4,      // constant media (and their isotropic phase functions)
   F_CHAINS = 8,     // translate / rotate-y wrappers
-  F_TEXTURES = 16,  // checker / noise / image textures
+  F_TEXTURES = 16,  // non-solid textures: checker (noise and image only with F_NOISE / F_IMAGE)
   F_SPECULAR = 32,  // metal / dielectric
-  F_ALL = 63,
-  F_SMALL = 64      // not a scene feature: the instantiation keeps DPrimInfo in LDS (<= RT_LDS_PRIMS)
+  F_SMALL = 64,     // not a scene feature: the instantiation keeps DPrimInfo in LDS (<= RT_LDS_PRIMS)
+  F_NOISE = 128,    // Perlin noise textures: tables in LDS, by far the most registers
+  F_IMAGE = 256,    // image textures: the only consumers of u/v (FP64 acos/atan2 for spheres)
+  F_ALL = 63 | 128 | 256
 };
 
 // 80 bytes. Spheres are intersected in FP64 (|oc|^2 - r^2 cancels catastrophically in FP32 for
