@@ -83,10 +83,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run")
         args.gpus = world
+    # Rehearsal hooks (a one-GPU box cannot run RCCL between two ranks on the same device):
+    # RTMI_ONE_GPU=1 puts every rank on device 0, RTMI_DIST_BACKEND=gloo swaps the collective backend.
+    backend = os.environ.get("RTMI_DIST_BACKEND", "nccl")
+    if os.environ.get("RTMI_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     cfg, flat = setup(args.scene, scene_seed=1)
     cam = build_camera(cfg, args.width / args.height)
@@ -105,8 +113,11 @@ def main():
         rays_total.append(st["rays"])
         return acc
 
+    # gloo has no reduce() for device tensors; all_reduce gives rank 0 the same sum
+    reduce_fn = None if backend == "nccl" else (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+
     def step():
-        render_distributed(render_fn, base, rank, world, args.split)
+        render_distributed(render_fn, base, rank, world, args.split, reduce_fn)
         if rank == 0:
             ctx.tonemap_device(acc.data_ptr(), W * H, spp, argb.data_ptr(), stream.cuda_stream)
 
@@ -161,6 +172,8 @@ def main():
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("k_render_hbm_bytes_per_launch")
+                if traffic is not None and world > 1:
+                    traffic = traffic / world  # measured at N = 1; a rank writes its own tiles' slots only
             except Exception:
                 traffic = None
         out = {
@@ -170,7 +183,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} {W}x{H} @{spp}spp depth 50 (core.clj:52-59 constants, "
                                    "reference cornell-box world)",
-                       "parallelism": f"{args.split}-shard x{world}" + (" + RCCL reduce(sum) to rank 0" if world > 1 else ""),
+                       "parallelism": f"{args.split}-shard x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} reduce(sum) to rank 0" if world > 1 else ""),
                        "samples_per_step": samples_per_step},
             "rays_per_sample": rays / (samples_per_step * args.steps),
             "Mrays_per_s": rays / elapsed / 1e6,
