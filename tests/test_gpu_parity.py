@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from raytracing_amd import abi
+from raytracing_amd.core import build_camera
 from util import ALL_SCENES, compare_hits, medium_uniform, probe_rays, scene_bundle
 
 pytestmark = pytest.mark.gpu
@@ -286,6 +287,37 @@ def test_full_size_cornell_properties(gpu_ctx):
     b = small / 64
     assert abs(a.mean() - b.mean()) < 0.05 * b.mean()  # ~1% MC noise + the (W-1) pixel-grid convention differs slightly with W
     assert (argb >> 24 == 0xFF).all()
+    sc.close()
+
+
+@pytest.mark.parametrize("name,W,H,spp,rays_lo,rays_hi", [
+    ("random-scene", 1200, 800, 4, 2.0, 3.5),    # BASELINE configs[1]: 489 spheres under a GPU-built BVH
+    ("final-scene", 3840, 2160, 2, 1.7, 3.2),    # BASELINE configs[4]: the 4K frame, BVHs + media + textures
+])
+def test_full_size_bvh_worlds_properties(gpu_ctx, name, W, H, spp, rays_lo, rays_hi):
+    """The other BASELINE sizes at a few samples per pixel, through size-independent properties:
+    every sample accounted for, finite non-negative radiance, sample slices that add up to the
+    whole, and block means that agree with a low-resolution render of the same world."""
+    cfg, flat, cam = scene_bundle(name)
+    cam = build_camera(cfg, W / H)
+    sc = gpu_ctx.scene(flat)
+    full, argb, st = sc.render(cam, abi.make_params(W, H, spp, 50, cfg["background"], seed=9))
+    assert st["samples"] == W * H * spp
+    assert np.isfinite(full).all() and (full >= 0).all()
+    assert rays_lo < st["rays"] / st["samples"] < rays_hi
+    assert (argb >> 24 == 0xFF).all()
+    # sample slices: [0, spp/2) + [spp/2, spp) == all samples (same per-sample streams; FP32 sums of
+    # two halves against one running sum)
+    half = spp // 2
+    a, _, _ = sc.render(cam, abi.make_params(W, H, half, 50, cfg["background"], seed=9))
+    b, _, _ = sc.render(cam, abi.make_params(W, H, spp - half, 50, cfg["background"], seed=9, sample_offset=half))
+    np.testing.assert_allclose(a + b, full, rtol=1e-5, atol=1e-5)
+    # block means against a 1/8-resolution render with 16x the samples
+    w8, h8 = W // 8, H // 8
+    small, _, _ = sc.render(cam, abi.make_params(w8, h8, spp * 16, 50, cfg["background"], seed=10))
+    blocks = full[:h8 * 8, :w8 * 8].reshape(h8, 8, w8, 8, 3).mean(axis=(1, 3)) / spp
+    ref = small / (spp * 16)
+    assert abs(blocks.mean() - ref.mean()) < 0.05 * ref.mean()
     sc.close()
 
 
