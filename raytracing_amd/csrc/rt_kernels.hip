@@ -63,6 +63,14 @@ __device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* ld
   return X;
 }
 
+// Sum of v over the 64 lanes of the wave (every lane must call it), returned in all lanes.
+__device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
+  unsigned long long x = v;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -151,6 +159,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
   // wave-uniform queue window [q_next, q_end) of work items taken from the global queue
   uint32_t q_next = 0, q_end = 0;
   bool q_dry = false;
+  int q_chunk = 0, q_tx0 = 0, q_ty0 = 0, q_s0 = 0, q_s1 = 0;  // what the window's items share
 
   // lane state
   bool have_item = false, active = false, done = false;
@@ -162,11 +171,25 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
   uint32_t bounce = 0;
   Rng g{0u, 0u, R.seed_lo, R.seed_hi};
   uint32_t n_rays = 0, n_samples = 0;
+  // HW_ID.wave_id (s_getreg id 4, offset 0, 4 bits): the wave's slot in its SIMD
+  uint32_t prio_tick = __builtin_amdgcn_s_getreg(6148);
 
 #ifdef RT_STAMPS
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsi = 0, c_queue = 0, c_cam = 0, c_hit = 0, c_shade = 0, c_iters = 0, c_groups = 0;
 #endif
   for (;;) {
+    // Rotate the issue priority among the waves of a SIMD, one step per iteration. With equal
+    // priorities the arbiter favours the oldest wave, and in a kernel that saturates the VALU the
+    // youngest waves then run several times slower (measured: 293 against 2 509 iterations per
+    // wave in one launch). The dynamic queue hides that until it runs dry; then the slow waves
+    // still sit in items they took long ago, which is what cost small jobs (one shard of eight)
+    // their efficiency.
+    switch (prio_tick++ & 3u) {
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
     RT_STAMP(ts0);
     bool need = !active && !done && !(have_item && s < s_end);
     if (need && have_item) {
@@ -178,16 +201,28 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
     unsigned long long mask = __ballot(need);
     if (mask != 0ull) {  // wave-uniform
       const RenderArgs RT_CONST* C = cold();
-      const uint32_t batch = (uint32_t)C->R.batch, n_items = (uint32_t)C->R.n_items;
       if (q_next == q_end && !q_dry) {
+        // A window is 64 consecutive items = the 64 pixels of ONE tile for ONE chunk (n_items is a
+        // multiple of 64), so the item is decoded once per window on wave-uniform values and a
+        // lane only adds its place in the tile.
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(C->queue, batch);
+        if (lane == 0) base = atomicAdd(C->queue, 64u);
         base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n_items) {
+        if (base >= (uint32_t)C->R.n_items) {
           q_dry = true;
         } else {
           q_next = base;
-          q_end = min(base + batch, n_items);
+          q_end = base + 64u;
+          const uint32_t items_per_chunk = (uint32_t)C->R.n_owned_tiles * 64u;
+          const uint32_t c = base / items_per_chunk;
+          const uint32_t rem = base - c * items_per_chunk;
+          const int tiles_x = C->R.tiles_x;
+          const int tile = C->R.shard_index + (int)(rem >> 6) * C->R.shard_count;
+          q_chunk = (int)c;
+          q_tx0 = (tile % tiles_x) * RT_TILE;
+          q_ty0 = (tile / tiles_x) * RT_TILE;
+          q_s0 = C->R.chunk_start[c];
+          q_s1 = C->R.chunk_start[c + 1];
         }
       }
       uint32_t avail = q_end - q_next;
@@ -195,19 +230,14 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       if (need) {
         uint32_t rank = lane_rank(mask);
         if (rank < avail) {
-          const uint32_t items_per_chunk = (uint32_t)C->R.n_owned_tiles * 64u;
-          const int tiles_x = C->R.tiles_x, width = C->R.width, height = C->R.height;
-          uint32_t item = q_next + rank;
-          chunk_id = (int)(item / items_per_chunk);
-          uint32_t rem = item - (uint32_t)chunk_id * items_per_chunk;
-          int tile = C->R.shard_index + (int)(rem >> 6) * C->R.shard_count;
-          int in_tile = (int)(rem & 63u);
-          px = (tile % tiles_x) * RT_TILE + (in_tile & 7);
-          py = (tile / tiles_x) * RT_TILE + (in_tile >> 3);
-          if (px < width && py < height) {
-            pix = py * width + px;
-            s = chunk_id * C->R.chunk;
-            s_end = min(C->R.spp, s + C->R.chunk);
+          const int in_tile = (int)((q_next & 63u) + rank);
+          px = q_tx0 + (in_tile & 7);
+          py = q_ty0 + (in_tile >> 3);
+          if (px < R.width && py < R.height) {
+            pix = py * R.width + px;
+            chunk_id = q_chunk;
+            s = q_s0;
+            s_end = q_s1;
             acc = mk(0.f, 0.f, 0.f);
             have_item = true;
           }
@@ -263,14 +293,23 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
   if (lane == 0) {
     atomicAdd(&stats[2 + 0], c_queue); atomicAdd(&stats[2 + 1], c_cam); atomicAdd(&stats[2 + 2], c_hit);
     atomicAdd(&stats[2 + 3], c_shade); atomicAdd(&stats[2 + 4], c_iters); atomicAdd(&stats[2 + 5], c_groups);
+    atomicMax(&stats[2 + 6], c_iters);                       // iterations of the busiest wave
+    atomicMax(&stats[2 + 7], ~0ull - c_iters);               // ... and (inverted) of the idlest
+    atomicAdd(&stats[2 + 8], c_iters * c_iters);             // for the spread
   }
 #endif
-  atomicAdd(&stats[0], (unsigned long long)n_samples);
-  atomicAdd(&stats[1], (unsigned long long)n_rays);
+  // One atomic per wave and counter, not per lane: half a million same-address atomics at the end
+  // of the kernel serialise in L2 and cost milliseconds.
+  {
+    unsigned long long ws = wave_sum(n_samples), wr = wave_sum(n_rays);
+    if (lane == 0) { atomicAdd(&stats[0], ws); atomicAdd(&stats[1], wr); }
+  }
   if constexpr (COUNT) {
 #pragma unroll
-    for (int e = 0; e < RT_EV_COUNT; ++e)
-      if (tally.ev[e]) atomicAdd(&stats[2 + e], (unsigned long long)tally.ev[e]);
+    for (int e = 0; e < RT_EV_COUNT; ++e) {
+      unsigned long long w = wave_sum(tally.ev[e]);
+      if (lane == 0 && w) atomicAdd(&stats[2 + e], w);
+    }
   }
 }
 

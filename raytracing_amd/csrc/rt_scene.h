@@ -19,6 +19,7 @@
 #define RT_MAX_CHAIN_OPS 4     // deepest Translate/RotateY nesting supported
 #define RT_BRUTE_MAX 16        // groups up to this size skip the BVH
 #define RT_MAX_PERLIN_LDS 8    // Perlin table sets staged in LDS
+#define RT_MAX_CHUNKS 128      // work items per pixel, at most
 #define RT_TILE 8              // pixels per tile edge; one wave64 = one 8x8 tile
 #define RT_PAIR_STRIDE 12      // dwords per pair record of DScene.brute_rects
 #define RT_PAIR_BATCH 3        // pair records the brute-force loop fetches per scalar-memory round trip
@@ -199,12 +200,11 @@ struct DRender {
   int32_t shard_index, shard_count;
   int32_t tiles_x, tiles_y;
   int32_t n_owned_tiles;   // tiles this call renders
-  int32_t chunk;           // samples per work item
-  int32_t n_chunks;        // ceil(spp / chunk)
+  int32_t n_chunks;        // a pixel's samples are split into n_chunks work items ("chunks")
   int32_t n_items;         // n_owned_tiles * 64 * n_chunks
-  int32_t batch;           // work items a wave takes from the global queue at once
   float bg[3];
   uint32_t seed_lo, seed_hi;
+  int32_t chunk_start[RT_MAX_CHUNKS + 1];  // chunk c covers samples [chunk_start[c], chunk_start[c+1])
 };
 
 #endif  // RT_SCENE_H

@@ -23,3 +23,9 @@ for name, v in (("queue/flush", q), ("camera regen", c), ("closest_hit", h), ("s
     print(f"  {name:14s} {v / it:9.1f} cycles per wave-iteration  {100 * v / tot:5.1f} %")
 print(f"  total          {tot / it:9.1f}")
 print(f"  of closest_hit: group loops {grp / it:9.1f}, record + unwind {(h - grp) / it:9.1f}")
+mx, mn_inv, sq = ev[6], ev[7], ev[8]
+if mx:
+    import math
+    n_waves = round(it * it / max(sq, 1)) if sq else 0  # exact only when all waves are equal; shown as a hint
+    mn = (1 << 64) - 1 - mn_inv
+    print(f"  iterations per wave: max {mx}, min {mn}, mean-square root {math.sqrt(sq / max(1, 7168)):.0f} (7168 waves assumed)")
