@@ -119,7 +119,9 @@ __device__ __forceinline__ bool path_step(const XC& X, const DRender& R, Ray& ra
 // the whole file): the lean instantiations are latency-bound on scalar loads and the RNG's
 // integer multiplies, which more resident waves hide.
 constexpr int waves_per_simd(uint32_t feat, bool count) {
-  if (feat & F_NOISE) return 2;
+  // the all-features kernel wants 211 registers; squeezing it costs a few spills but the long BVH
+  // walks gain more from a third and fourth wave than the texture worlds lose
+  if (feat & F_NOISE) return count ? 2 : ((feat & F_DEEP) ? 4 : 3);
   if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : 4;
   return count ? 4 : RT_WAVES_LEAN;
 }
@@ -401,13 +403,14 @@ constexpr uint32_t V_RECT = F_CHAINS | F_SMALL;
 constexpr uint32_t V_SMOKE = F_CHAINS | F_MEDIA | F_SMALL;
 constexpr uint32_t V_SPH = F_SPHERES | F_BVH | F_SPECULAR | F_TEXTURES;
 constexpr uint32_t V_ALL = F_ALL;
+constexpr uint32_t V_ALL_DEEP = F_ALL | F_DEEP;  // everything, for worlds with BVHs
 
 int pick_variant(const DScene& S) {
   const bool small = S.n_prims <= RT_LDS_PRIMS && S.n_chains <= RT_LDS_CHAINS;
   if (small && (S.features & ~V_RECT) == 0) return 0;
   if (small && (S.features & ~V_SMOKE) == 0) return 1;
   if ((S.features & ~V_SPH) == 0) return 2;
-  return 3;
+  return (S.features & F_BVH) ? 4 : 3;
 }
 
 size_t shade_lds_bytes(const DScene& S, int block) {
@@ -427,6 +430,8 @@ auto with_render_kernel(const DScene& S, bool count, F&& f) {
     case 4: return f(k_render<V_SPH, false>);
     case 5: return f(k_render<V_SPH, true>);
     case 6: return f(k_render<V_ALL, false>);
+    case 7: return f(k_render<V_ALL, true>);
+    case 8: return f(k_render<V_ALL_DEEP, false>);
     default: return f(k_render<V_ALL, true>);
   }
 }

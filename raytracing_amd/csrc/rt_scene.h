@@ -37,7 +37,8 @@ enum : uint32_t {
   F_SMALL = 64,     // not a scene feature: the instantiation keeps DPrimInfo in LDS (<= RT_LDS_PRIMS)
   F_NOISE = 128,    // Perlin noise textures: tables in LDS, by far the most registers
   F_IMAGE = 256,    // image textures: the only consumers of u/v (FP64 acos/atan2 for spheres)
-  F_ALL = 63 | 128 | 256
+  F_ALL = 63 | 128 | 256,
+  F_DEEP = 512      // not a scene feature: same code, compiled for more waves per SIMD (BVH worlds)
 };
 
 // 80 bytes. Spheres are intersected in FP64 (|oc|^2 - r^2 cancels catastrophically in FP32 for
