@@ -122,7 +122,7 @@ constexpr int waves_per_simd(uint32_t feat, bool count) {
   // the all-features kernel wants 211 registers; squeezing it costs a few spills but the long BVH
   // walks gain more from a third and fourth wave than the texture worlds lose
   if (feat & F_NOISE) return count ? 2 : ((feat & F_DEEP) ? 4 : 3);
-  if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : 4;
+  if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : 5;
   return count ? 4 : RT_WAVES_LEAN;
 }
 
