@@ -14,6 +14,8 @@
 #include <set>
 #include <string>
 #include <utility>
+#include <array>
+#include <functional>
 #include <vector>
 
 #include "../../include/rtmi.h"
@@ -449,12 +451,62 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
     H.rc = c; H.rs = s; H.bx = b[0]; H.by = b[1]; H.bz = b[2];
     G.rc = (float)c; G.rs = (float)s; G.bx = (float)b[0]; G.by = (float)b[1]; G.bz = (float)b[2];
   };
+  // extent of a primitive's bounding box along its longest axis, and its centre
+  auto prim_extent = [&](int pi, double c[3]) {
+    const int t = d->prim_type[pi];
+    const double* pd = d->prim_d + (size_t)pi * RT_PRIM_STRIDE;
+    double lo[3], hi[3];
+    if (t == RT_PRIM_SPHERE) {
+      for (int a = 0; a < 3; ++a) { lo[a] = pd[a] - std::fabs(pd[3]); hi[a] = pd[a] + std::fabs(pd[3]); }
+    } else if (t == RT_PRIM_MOVING_SPHERE) {
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = std::min(pd[a], pd[3 + a]) - std::fabs(pd[8]);
+        hi[a] = std::max(pd[a], pd[3 + a]) + std::fabs(pd[8]);
+      }
+    } else {
+      const int ax_a = t == RT_PRIM_YZ_RECT ? 1 : 0, ax_b = t == RT_PRIM_XY_RECT ? 1 : 2, ax_k = 3 - ax_a - ax_b;
+      lo[ax_a] = std::min(pd[0], pd[1]); hi[ax_a] = std::max(pd[0], pd[1]);
+      lo[ax_b] = std::min(pd[2], pd[3]); hi[ax_b] = std::max(pd[2], pd[3]);
+      lo[ax_k] = hi[ax_k] = pd[4];
+    }
+    double e = 0.0;
+    for (int a = 0; a < 3; ++a) { c[a] = 0.5 * (lo[a] + hi[a]); e = std::max(e, hi[a] - lo[a]); }
+    return e;
+  };
+  std::function<void(int, std::vector<int>)> emit_one;
   auto emit_groups = [&](const Sink& sink) {
     for (int chain : sink.chain_order) {
       std::vector<int> list = sink.prims.at(chain);
       // by type, stably: XY, XZ, YZ rects, then spheres (scan order kept within a type)
       auto type_rank = [&](int pi) { int t = d->prim_type[pi]; return t >= RT_PRIM_XY_RECT ? t - RT_PRIM_XY_RECT : 3; };
       std::stable_sort(list.begin(), list.end(), [&](int x, int y) { return type_rank(x) < type_rank(y); });
+      // A BVH over Morton codes is only as good as its primitives are alike in size: one huge
+      // primitive (the r = 1000 ground spheres of the random-spheres world) inflates the box of
+      // every ancestor it has and stretches the Morton grid until the small primitives share a few
+      // cells. Primitives much larger than the spread of the others' centres go into a brute-force
+      // group of their own, scanned BEFORE the tree: the tree's leaf test applies the tie rule on
+      // ranks explicitly, so an exact tie across the two groups still falls as in one scan.
+      if ((int)list.size() > RT_BRUTE_MAX) {
+        std::vector<double> ext(list.size());
+        std::vector<std::array<double, 3>> ctr(list.size());
+        for (size_t i = 0; i < list.size(); ++i) ext[i] = prim_extent(list[i], ctr[i].data());
+        std::vector<double> sorted = ext;
+        std::nth_element(sorted.begin(), sorted.begin() + (long)sorted.size() / 2, sorted.end());
+        const double median = sorted[sorted.size() / 2];
+        std::vector<int> huge, rest;
+        for (size_t i = 0; i < list.size(); ++i)
+          (ext[i] > 16.0 * median && median > 0.0 ? huge : rest).push_back(list[i]);
+        if (!huge.empty() && (int)huge.size() <= RT_BRUTE_MAX && !rest.empty()) {
+          emit_one(chain, huge);
+          emit_one(chain, rest);
+          continue;
+        }
+      }
+      emit_one(chain, list);
+    }
+  };
+  emit_one = [&](int chain, std::vector<int> list) {
+    {
       DGroup G;
       DGroup64 H;
       std::memset(&G, 0, sizeof G);
