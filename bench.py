@@ -168,10 +168,20 @@ def main():
         my_samples = samples_per_step / world
         achieved = flop_per_sample * my_samples / (kern_ms_max * 1e-3) / 1e12
         traffic = None
+        valu_cycles_per_inst = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_render_hbm_bytes_per_launch")
+                prof = json.load(open(tpath))
+                traffic = prof.get("k_render_hbm_bytes_per_launch")
+                # SIMD cycles available per VALU wave-instruction of the profiled launch (same workload
+                # at N = 1): the measured issue cost is 2.7 cycles for FMA-class and 4.5 for
+                # compare/select/min/max/convert/FP64/SGPR-operand instructions, so a value near 3.3
+                # means the VALU issue slots are full
+                if world == 1 and prof.get("valu_wave_insts_per_launch"):
+                    props = torch.cuda.get_device_properties(device)
+                    simd_cycles = kern_ms_max * 1e-3 * 2.4e9 * props.multi_processor_count * 4
+                    valu_cycles_per_inst = simd_cycles / prof["valu_wave_insts_per_launch"]
                 if traffic is not None and world > 1:
                     traffic = traffic / world  # measured at N = 1; a rank writes its own tiles' slots only
             except Exception:
@@ -191,6 +201,7 @@ def main():
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                          "kernel": "rt::k_render<FEAT, false> (the feature-specialised instantiation this scene selects)", "kernel_ms": kern_ms_max,
+                         "simd_cycles_per_valu_instruction": valu_cycles_per_inst,
                          "note": "algorithmic FLOP per event x event counts of the counting build of the same "
                                  "kernel, per GPU, over that GPU's HIP-event kernel time; the path is branchy "
                                  "FP32 VALU work, neither HBM- nor MFMA-bound"},
