@@ -220,6 +220,18 @@ def test_tile_sharding_is_bit_exact_and_sample_slices_add_up(gpu_ctx):
     np.testing.assert_allclose(a + b, full, rtol=2e-6, atol=1e-6)  # same samples, other FP32 order
     again, _, _ = sc.render(cam, abi.make_params(W, H, spp, 50, cfg["background"], seed=3))
     np.testing.assert_array_equal(again, full)     # deterministic run to run
+    # above 128 spp the work items follow the tiered schedule (equal chunks, then shrinking tiers):
+    # still a function of spp alone, so shards stay bit-exact, and every sample is rendered once
+    big, _, st = sc.render(cam, abi.make_params(W, H, 333, 50, cfg["background"], seed=3))
+    assert st["samples"] == W * H * 333
+    acc = np.zeros_like(big)
+    for idx in range(3):
+        part, _, _ = sc.render(cam, abi.make_params(W, H, 333, 50, cfg["background"], seed=3, shard_index=idx, shard_count=3))
+        acc += part
+    np.testing.assert_array_equal(acc, big)
+    lo, _, _ = sc.render(cam, abi.make_params(W, H, 133, 50, cfg["background"], seed=3))
+    hi, _, _ = sc.render(cam, abi.make_params(W, H, 200, 50, cfg["background"], seed=3, sample_offset=133))
+    np.testing.assert_allclose(lo + hi, big, rtol=1e-5, atol=1e-5)
     sc.close()
 
 
