@@ -663,12 +663,36 @@ RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax,
   const float INF = __builtin_inff();
   const int first_group = M.first_group, n_groups = M.n_groups;
   // rec1 = hit boundary (-inf, +inf); rec2 = hit boundary (rec1.t + 0.0001, +inf)
-  Best b1{INF, -1};
-  for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, -INF, b1, tally);
-  if (b1.prim < 0) return false;
-  Best b2{INF, -1};
-  for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, b1.t + 0.0001f, b2, tally);
-  if (b2.prim < 0) return false;
+  Best b1{INF, -1}, b2{INF, -1};
+  bool single_sphere = false;
+  if constexpr (X::has(F_SPHERES)) {
+    // A boundary that is one sphere (every medium the reference ships): both queries read the
+    // same two roots, so the quadratic is solved once and the range tests of sphere_t are
+    // applied twice, exactly as two calls would.
+    const DGroup RT_CONST& G = cptr(S.groups)[first_group];
+    single_sphere = n_groups == 1 && G.bvh_root < 0 && G.n_sph == 1 && (G.n_xy | G.n_xz | G.n_yz) == 0;
+    if (single_sphere) {
+      const RayX r = group_ray<X>(S, first_group, G.flags, G.rc, G.rs, G.bx, G.by, G.bz, wr, tally);
+      const DPrim RT_CONST& P = cptr(S.prims)[G.first_prim];
+      double root1, root2;
+      if (!sphere_roots(P, prim_type(P.type), r, root1, root2, tally)) return false;
+      const double NINF = -(double)INF;
+      if (root1 > NINF && (float)root1 < INF) b1.t = (float)root1;
+      else if (root2 > NINF && (float)root2 < INF) b1.t = (float)root2;
+      else return false;
+      const double tmin2 = (double)(b1.t + 0.0001f);
+      if (root1 > tmin2 && (float)root1 < INF) b2.t = (float)root1;
+      else if (root2 > tmin2 && (float)root2 < INF) b2.t = (float)root2;
+      else return false;
+      b1.prim = b2.prim = G.first_prim;
+    }
+  }
+  if (!single_sphere) {
+    for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, -INF, b1, tally);
+    if (b1.prim < 0) return false;
+    for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, b1.t + 0.0001f, b2, tally);
+    if (b2.prim < 0) return false;
+  }
   float t1 = (b1.t < tmin) ? tmin : b1.t;
   float t2 = (b2.t > tmax) ? tmax : b2.t;
   if (!(t1 < t2)) return false;
