@@ -1,0 +1,185 @@
+/*
+ * cornell.c — the C ABI of librtmi.so driven from plain C, no Python, no torch:
+ * builds the reference's cornell-box world (scenes.clj:71-87) as an rt_scene_desc by hand,
+ * renders it with the constants of -main (core.clj:52-59,89-91) and writes a binary PPM
+ * (top row first, i.e. the row flip of core.clj:123-126 without its margins).
+ *
+ *   cornell [width height spp out.ppm [argb.bin]]      defaults: 256 256 64 cornell.ppm
+ *
+ * Build: make -C raytracing_amd/csrc example
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rtmi.h"
+
+#define MAX_PRIMS 32
+#define MAX_NODES 64
+
+static int32_t prim_type[MAX_PRIMS], prim_mat[MAX_PRIMS];
+static double prim_d[MAX_PRIMS * RT_PRIM_STRIDE];
+static int32_t node_kind[MAX_NODES], node_i[MAX_NODES * RT_NODE_ISTRIDE], node_children[MAX_NODES];
+static double node_d[MAX_NODES * RT_NODE_DSTRIDE];
+static int n_prims, n_nodes, n_children;
+
+/* rectangles.clj: xy-rect x0 x1 y0 y1 k / xz-rect x0 x1 z0 z1 k / yz-rect y0 y1 z0 z1 k (k is ^long) */
+static int rect(int type, double a0, double a1, double b0, double b1, double k, int mat) {
+  double* d = prim_d + (size_t)n_prims * RT_PRIM_STRIDE;
+  prim_type[n_prims] = type;
+  prim_mat[n_prims] = mat;
+  d[0] = a0; d[1] = a1; d[2] = b0; d[3] = b1; d[4] = (double)(long)k;
+  node_kind[n_nodes] = RT_NODE_PRIM;
+  node_i[n_nodes * RT_NODE_ISTRIDE] = n_prims++;
+  return n_nodes++;
+}
+
+static int list(const int* kids, int n) {
+  node_kind[n_nodes] = RT_NODE_LIST;
+  node_i[n_nodes * RT_NODE_ISTRIDE] = n_children;
+  node_i[n_nodes * RT_NODE_ISTRIDE + 1] = n;
+  for (int i = 0; i < n; ++i) node_children[n_children++] = kids[i];
+  return n_nodes++;
+}
+
+/* box.clj:15-24: the six sides in the reference's order */
+static int box(double x0, double y0, double z0, double x1, double y1, double z1, int mat) {
+  int s[6];
+  s[0] = rect(RT_PRIM_XY_RECT, x0, x1, y0, y1, z1, mat);
+  s[1] = rect(RT_PRIM_XY_RECT, x0, x1, y0, y1, z0, mat);
+  s[2] = rect(RT_PRIM_XZ_RECT, x0, x1, z0, z1, y1, mat);
+  s[3] = rect(RT_PRIM_XZ_RECT, x0, x1, z0, z1, y0, mat);
+  s[4] = rect(RT_PRIM_YZ_RECT, y0, y1, z0, z1, x1, mat);
+  s[5] = rect(RT_PRIM_YZ_RECT, y0, y1, z0, z1, x0, mat);
+  return list(s, 6);
+}
+
+static int rotate_y(int child, double degrees) { /* rotate.clj:51-54 */
+  double r = degrees * 0.017453292519943295;
+  node_kind[n_nodes] = RT_NODE_ROTATE_Y;
+  node_i[n_nodes * RT_NODE_ISTRIDE] = child;
+  node_d[n_nodes * RT_NODE_DSTRIDE] = sin(r);
+  node_d[n_nodes * RT_NODE_DSTRIDE + 1] = cos(r);
+  return n_nodes++;
+}
+
+static int translate(int child, double x, double y, double z) { /* translate.clj:23-24 */
+  node_kind[n_nodes] = RT_NODE_TRANSLATE;
+  node_i[n_nodes * RT_NODE_ISTRIDE] = child;
+  node_d[n_nodes * RT_NODE_DSTRIDE] = x;
+  node_d[n_nodes * RT_NODE_DSTRIDE + 1] = y;
+  node_d[n_nodes * RT_NODE_DSTRIDE + 2] = z;
+  return n_nodes++;
+}
+
+static void unit(double v[3]) { /* base.clj:39-40 */
+  double k = 1.0 / sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  v[0] *= k; v[1] *= k; v[2] *= k;
+}
+
+/* camera.clj:7-33 */
+static void camera(const double from[3], const double at[3], const double vup[3], double vfov, double aspect,
+                   double aperture, double focus, double t0, double t1, rt_camera* c) {
+  double theta = vfov * 0.017453292519943295, h = tan(theta * 0.5);
+  double vh = h * 2.0, vw = aspect * vh;
+  double w[3] = {from[0] - at[0], from[1] - at[1], from[2] - at[2]};
+  unit(w);
+  double u[3] = {vup[1] * w[2] - vup[2] * w[1], vup[2] * w[0] - vup[0] * w[2], vup[0] * w[1] - vup[1] * w[0]};
+  unit(u);
+  double v[3] = {w[1] * u[2] - w[2] * u[1], w[2] * u[0] - w[0] * u[2], w[0] * u[1] - w[1] * u[0]};
+  for (int a = 0; a < 3; ++a) {
+    c->origin[a] = from[a];
+    c->horizontal[a] = u[a] * (focus * vw);
+    c->vertical[a] = v[a] * (focus * vh);
+    c->lower_left_corner[a] = ((from[a] - c->horizontal[a] * 0.5) - c->vertical[a] * 0.5) - w[a] * focus;
+    c->u[a] = u[a]; c->v[a] = v[a]; c->w[a] = w[a];
+  }
+  c->lens_radius = aperture / 2;
+  c->time0 = t0; c->time1 = t1;
+}
+
+#define CHECK(call)                                                      \
+  do {                                                                   \
+    int rc_ = (call);                                                    \
+    if (rc_ != RT_OK) {                                                  \
+      fprintf(stderr, "%s -> %d: %s\n", #call, rc_, rt_last_error());    \
+      return 1;                                                          \
+    }                                                                    \
+  } while (0)
+
+int main(int argc, char** argv) {
+  int W = argc > 1 ? atoi(argv[1]) : 256, H = argc > 2 ? atoi(argv[2]) : 256, spp = argc > 3 ? atoi(argv[3]) : 64;
+  const char* out = argc > 4 ? argv[4] : "cornell.ppm";
+  const char* raw = argc > 5 ? argv[5] : NULL;
+
+  /* materials: red, white, green Lambertians over solid colours, one diffuse light (scenes.clj:72-75) */
+  enum { RED, WHITE, GREEN, LIGHT };
+  int32_t mat_type[4] = {RT_MAT_LAMBERTIAN, RT_MAT_LAMBERTIAN, RT_MAT_LAMBERTIAN, RT_MAT_DIFFUSE_LIGHT};
+  int32_t mat_tex[4] = {0, 1, 2, 3};
+  double mat_d[4 * RT_MAT_DSTRIDE] = {0};
+  int32_t tex_type[4] = {RT_TEX_SOLID, RT_TEX_SOLID, RT_TEX_SOLID, RT_TEX_SOLID};
+  int32_t tex_i[4 * RT_TEX_ISTRIDE] = {0};
+  double tex_d[4 * RT_TEX_DSTRIDE] = {0.65, 0.05, 0.05, 0, 0.73, 0.73, 0.73, 0, 0.12, 0.45, 0.15, 0, 15, 15, 15, 0};
+
+  int world[8];
+  world[0] = rect(RT_PRIM_YZ_RECT, 0, 555, 0, 555, 555, GREEN);
+  world[1] = rect(RT_PRIM_YZ_RECT, 0, 555, 0, 555, 0, RED);
+  world[2] = rect(RT_PRIM_XZ_RECT, 213, 343, 227, 332, 554, LIGHT);
+  world[3] = rect(RT_PRIM_XZ_RECT, 0, 555, 0, 555, 0, WHITE);
+  world[4] = rect(RT_PRIM_XZ_RECT, 0, 555, 0, 555, 555, WHITE);
+  world[5] = rect(RT_PRIM_XY_RECT, 0, 555, 0, 555, 555, WHITE);
+  world[6] = translate(rotate_y(box(0, 0, 0, 165, 330, 165, WHITE), 15), 265, 0, 295);
+  world[7] = translate(rotate_y(box(0, 0, 0, 165, 165, 165, WHITE), -18), 130, 0, 65);
+  int root = list(world, 8);
+
+  rt_scene_desc d;
+  memset(&d, 0, sizeof d);
+  d.abi_version = RTMI_ABI_VERSION;
+  d.n_prims = n_prims; d.prim_type = prim_type; d.prim_d = prim_d; d.prim_mat = prim_mat;
+  d.n_nodes = n_nodes; d.node_kind = node_kind; d.node_i = node_i; d.node_d = node_d;
+  d.n_children = n_children; d.node_children = node_children; d.root = root; d.n_media = 0;
+  d.n_mats = 4; d.mat_type = mat_type; d.mat_d = mat_d; d.mat_tex = mat_tex;
+  d.n_tex = 4; d.tex_type = tex_type; d.tex_d = tex_d; d.tex_i = tex_i;
+
+  rt_camera cam;
+  const double from[3] = {278, 278, -800}, at[3] = {278, 278, 0}, vup[3] = {0, 1, 0};
+  camera(from, at, vup, 40.0, (double)W / (double)H, 0.0, 10.0, 0.0, 1.0, &cam);
+
+  rt_params p;
+  memset(&p, 0, sizeof p);
+  p.width = W; p.height = H; p.spp = spp; p.max_depth = 50; p.shard_count = 1;
+  p.seed = 0x5EED0001ull;
+
+  rt_ctx* ctx = NULL;
+  rt_scene* scene = NULL;
+  CHECK(rt_init(0, &ctx));
+  CHECK(rt_scene_create(ctx, &d, &scene));
+  uint32_t* argb = (uint32_t*)malloc((size_t)W * H * 4);
+  rt_stats st;
+  CHECK(rt_render(ctx, scene, &cam, &p, NULL, argb, &st));
+  fprintf(stderr, "%llu samples, %llu rays, kernel %.3f ms (%.0f Msamples/s)\n", (unsigned long long)st.samples,
+          (unsigned long long)st.rays, st.kernel_ms, (double)st.samples / st.kernel_ms / 1e3);
+
+  FILE* f = fopen(out, "wb");
+  if (!f) { perror(out); return 1; }
+  fprintf(f, "P6\n%d %d\n255\n", W, H);
+  for (int y = H - 1; y >= 0; --y)
+    for (int x = 0; x < W; ++x) {
+      uint32_t c = argb[(size_t)y * W + x];
+      unsigned char rgb[3] = {(unsigned char)(c >> 16), (unsigned char)(c >> 8), (unsigned char)c};
+      fwrite(rgb, 1, 3, f);
+    }
+  fclose(f);
+  if (raw) {
+    f = fopen(raw, "wb");
+    if (!f) { perror(raw); return 1; }
+    fwrite(argb, 4, (size_t)W * H, f);
+    fclose(f);
+  }
+  free(argb);
+  rt_scene_destroy(scene);
+  rt_shutdown(ctx);
+  return 0;
+}

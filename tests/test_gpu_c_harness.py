@@ -1,0 +1,39 @@
+"""The C ABI driven from plain C (examples/cornell.c, built by `make -C raytracing_amd/csrc`): a
+process with no Python and no torch in it builds the cornell-box description by hand, renders it and
+must produce the very pixels the Python host layer gets for the same request."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracing_amd import abi
+from util import scene_bundle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "cornell")
+
+
+def test_plain_c_program_renders_the_same_pixels(gpu_ctx, tmp_path):
+    assert os.path.exists(EXE), "examples/cornell is built by make -C raytracing_amd/csrc"
+    W, H, spp = 72, 40, 24
+    ppm, raw = str(tmp_path / "c.ppm"), str(tmp_path / "c.bin")
+    env = dict(os.environ)
+    env.pop("LD_LIBRARY_PATH", None)  # the program finds librtmi.so through its rpath
+    r = subprocess.run([EXE, str(W), str(H), str(spp), ppm, raw], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr
+    c_argb = np.fromfile(raw, dtype=np.uint32).reshape(H, W)
+    cfg, flat, _ = scene_bundle("cornell-box")
+    from raytracing_amd.core import build_camera
+    cam = build_camera(cfg, W / H)
+    sc = gpu_ctx.scene(flat)
+    _, argb, st = sc.render(cam, abi.make_params(W, H, spp, 50, cfg["background"], seed=0x5EED0001))
+    sc.close()
+    np.testing.assert_array_equal(c_argb, np.asarray(argb, dtype=np.uint32).reshape(H, W))
+    with open(ppm, "rb") as f:
+        assert f.readline() == b"P6\n" and f.readline() == f"{W} {H}\n".encode() and f.readline() == b"255\n"
+        body = np.frombuffer(f.read(), dtype=np.uint8).reshape(H, W, 3)
+    top = c_argb[H - 1]  # the PPM's first row is the image's top row = y = H-1
+    np.testing.assert_array_equal(body[0, :, 0], (top >> 16) & 255)
+    assert f"{W * H * spp} samples" in r.stderr
