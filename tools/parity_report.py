@@ -46,4 +46,4 @@ for name in ALL_SCENES:
           f"{md.mean():9.5f} {mc.mean():9.5f}", flush=True)
     sc.close()
 print(f"renders: {W}x{H}, {BATCHES} batches x {SPP} spp per side, different seeds on the two sides; z = |mean difference| / standard error "
-      "(t-distributed, 10 dof: P(|z|>3) = 1.3 %). hit records: 20000 probe rays per world; error columns are the 99.99th percentile (relative as in tests/test_gpu_parity.py), '>1e-5' counts the rays beyond the bar in any field (knife-edge rays; final-scene: u/v on coincident box faces, see DESIGN).")
+      "(t-distributed, 10 dof: P(|z|>3) = 1.3 %). hit records: 20000 probe rays per world; error columns are the 99.99th percentile (relative as in tests/test_gpu_parity.py), '>1e-5' counts the rays beyond the bar in any field (knife-edge rays; final-scene: u/v on coincident faces of adjacent ground boxes, which the reference resolves through the shape of its own BVH).")
