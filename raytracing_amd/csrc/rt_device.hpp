@@ -177,9 +177,9 @@ struct Ctx {
 // --------------------------------------------------------------------------- primitives
 struct Best {
   float t;   // closest so far (the reference's closest-so-far, base.clj:94-97)
-  int prim;  // device primitive index | RT_SECOND_ROOT; -1 = none; <= -2 = medium (-2 - m)
+  int prim;  // device primitive index; -1 = none; <= -2 = medium (-2 - m)
+  double root;  // a sphere's winning root in FP64, for its record (base.clj:243-246 take the FP64 root)
 };
-#define RT_SECOND_ROOT (1 << 30)  // a sphere won with its second candidate root
 
 RT_DEV int prim_type(int type_group) { return type_group & 15; }
 RT_DEV int prim_group(int type_group) { return type_group >> 4; }
@@ -254,14 +254,14 @@ RT_DEV bool sphere_roots(const PRIM& P, int type, const RayX& r, double& root1, 
 // The range tests of base.clj:242,248: t_min < root (FP64) and (float)root < t_max (strict, so
 // the earlier of two coincident spheres keeps an exact tie).
 template <class PRIM, class T>
-RT_DEV bool sphere_t(const PRIM& P, int type, const RayX& r, double tmin, float tmax, float& t_out, bool& second,
+RT_DEV bool sphere_t(const PRIM& P, int type, const RayX& r, double tmin, float tmax, float& t_out, double& root_out,
                      T& tally) {
   double root1, root2;
   if (!sphere_roots(P, type, r, root1, root2, tally)) return false;
   tally.template add<RT_EV_SPHERE_ROOT>();
-  if (root1 > tmin && (float)root1 < tmax) { t_out = (float)root1; second = false; return true; }
+  if (root1 > tmin && (float)root1 < tmax) { t_out = (float)root1; root_out = root1; return true; }
   tally.template add<RT_EV_SPHERE_ROOT>();
-  if (root2 > tmin && (float)root2 < tmax) { t_out = (float)root2; second = true; return true; }
+  if (root2 > tmin && (float)root2 < tmax) { t_out = (float)root2; root_out = root2; return true; }
   return false;
 }
 
@@ -280,7 +280,7 @@ RT_DEV void test_prim_any_order(const DScene& S, int idx, const RayX& r, float t
   const DPrim RT_CONST& P = prims[idx];
   const int type = prim_type(P.type);
   float t;
-  bool second = false;
+  double root = 0.0;
   if (is_rect(type)) {
     tally.template add<RT_EV_RECT_TEST>();
     // The orientation differs per lane here: select the ray's components. The copies are made
@@ -295,16 +295,16 @@ RT_DEV void test_prim_any_order(const DScene& S, int idx, const RayX& r, float t
     const bool ok = rect_ok_axes(P.f[0], P.f[1], P.f[2], P.f[3], P.f[4], oc, ic, oa, da, ob, db, tmin, best.t, t);
     if (!ok) return;
     if (t == best.t && best.prim >= 0) {
-      int bi = best.prim & ~RT_SECOND_ROOT;
+      const int bi = best.prim;
       if (!wins_tie(type, idx, prim_type(prims[bi].type), bi)) return;
     }
   } else {
     if constexpr (X::has(F_SPHERES)) {
-      if (!sphere_t(P, type, r, (double)tmin, __builtin_inff(), t, second, tally)) return;
+      if (!sphere_t(P, type, r, (double)tmin, __builtin_inff(), t, root, tally)) return;
       if (t > best.t) return;
       if (t == best.t) {
         if (best.prim < 0) return;  // t == t_max with nothing hit yet: the strict test fails
-        int bi = best.prim & ~RT_SECOND_ROOT;
+        const int bi = best.prim;
         if (!wins_tie(type, idx, prim_type(prims[bi].type), bi)) return;
       }
     } else {
@@ -312,7 +312,8 @@ RT_DEV void test_prim_any_order(const DScene& S, int idx, const RayX& r, float t
     }
   }
   best.t = t;
-  best.prim = second ? (idx | RT_SECOND_ROOT) : idx;
+  best.prim = idx;
+  best.root = root;
 }
 
 // ------------------------------------------------------------------------------- chains
@@ -502,10 +503,11 @@ RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best
       for (int i = 0; i < n_sph; ++i) {
         const DPrim RT_CONST& P = prims[first + i];
         float t = 0.f;
-        bool second = false;
-        bool ok = sphere_t(P, prim_type(P.type), r, (double)tmin, best.t, t, second, tally);
+        double root = 0.0;
+        bool ok = sphere_t(P, prim_type(P.type), r, (double)tmin, best.t, t, root, tally);
         best.t = ok ? t : best.t;
-        best.prim = ok ? ((first + i) | (second ? RT_SECOND_ROOT : 0)) : best.prim;
+        best.prim = ok ? first + i : best.prim;
+        best.root = ok ? root : best.root;
       }
     }
   }
@@ -551,7 +553,7 @@ RT_DEV void sphere_uv(D3 n, float& u, float& v) {
 
 // The HitRecord of primitive `prim` (info I) for the (chain-space) ray r at parameter t.
 template <class X, class T>
-RT_DEV void prim_record(const DScene& S, int prim, const DPrimInfo& I, const RayX& r, float t, bool second_root,
+RT_DEV void prim_record(const DScene& S, int prim, const DPrimInfo& I, const RayX& r, float t, double root,
                         bool want_uv, Rec& rec, T& tally) {
   const int type = prim_type(I.type_group);
   rec.mat = I.mat;
@@ -579,13 +581,9 @@ RT_DEV void prim_record(const DScene& S, int prim, const DPrimInfo& I, const Ray
     rec.p = p;
   } else {
     if constexpr (X::has(F_SPHERES)) {
-      // base.clj:243-246 in FP64 from the FP64 root (recomputed: only the winner pays for it)
+      // base.clj:243-246 in FP64 from the FP64 root the winning test kept
       tally.template add<RT_EV_SPHERE_RECORD>();
       const DPrim RT_CONST& P = cptr(S.prims)[prim];
-      Tally<false> quiet;
-      double root1 = (double)t, root2 = (double)t;
-      sphere_roots(P, type, r, root1, root2, quiet);
-      double root = second_root ? root2 : root1;
       D3 c = sphere_center(P, type, r.tm);
       double inv_r = 1.0 / sphere_radius(P, type);
       D3 o64 = rayx_o64(r), d64 = rayx_d64(r);
@@ -663,7 +661,7 @@ RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax,
   const float INF = __builtin_inff();
   const int first_group = M.first_group, n_groups = M.n_groups;
   // rec1 = hit boundary (-inf, +inf); rec2 = hit boundary (rec1.t + 0.0001, +inf)
-  Best b1{INF, -1}, b2{INF, -1};
+  Best b1{INF, -1, 0.0}, b2{INF, -1, 0.0};
   bool single_sphere = false;
   if constexpr (X::has(F_SPHERES)) {
     // A boundary that is one sphere (every medium the reference ships): both queries read the
@@ -721,7 +719,7 @@ RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, con
                         const float* medium_xi, bool skip_media, bool want_uv_always, Rec& rec, T& tally,
                         unsigned long long* g_stamp_inner = nullptr) {
   const DScene& S = ctx.S;
-  Best best{tmax, -1};
+  Best best{tmax, -1, 0.0};
   const int n_surface = S.n_surface_groups;
   for (int gi = 0; gi < n_surface; ++gi) group_hit(ctx, gi, wr, tmin, best, tally);
 #ifdef RT_STAMPS
@@ -741,13 +739,12 @@ RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, con
   }
   if (best.prim == -1) return false;
   if (!X::has(F_MEDIA) || best.prim >= 0) {
-    const bool second_root = (best.prim & RT_SECOND_ROOT) != 0;
-    const int prim = best.prim & ~RT_SECOND_ROOT;
+    const int prim = best.prim;
     const DPrimInfo I = load_info(ctx, prim);
     RayX rx = group_ray<X>(S, prim_group(I.type_group), I.gflags, I.rc, I.rs, I.bx, I.by, I.bz, wr, tally);
     bool want_uv = want_uv_always;
     if constexpr (X::has(F_IMAGE)) want_uv = want_uv || (I.mflags & DMAT_NEEDS_UV) != 0;
-    prim_record<X>(S, prim, I, rx, best.t, second_root, want_uv, rec, tally);
+    prim_record<X>(S, prim, I, rx, best.t, best.root, want_uv, rec, tally);
     chain_unwind(ctx, I.chain, wr.d, rec, tally);
   } else {
     if constexpr (X::has(F_MEDIA)) {
