@@ -192,7 +192,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} {W}x{H} @{spp}spp depth 50 (core.clj:52-59 constants, "
-                                   "reference cornell-box world)",
+                                   f"reference {args.scene} world)",
                        "parallelism": f"{args.split}-shard x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} reduce(sum) to rank 0" if world > 1 else ""),
                        "samples_per_step": samples_per_step},
             "rays_per_sample": rays / (samples_per_step * args.steps),
