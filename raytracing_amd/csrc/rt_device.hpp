@@ -75,11 +75,13 @@ template <bool ON>
 struct Tally;
 template <>
 struct Tally<false> {
+  static constexpr bool on = false;
   template <int E>
   RT_DEV void add(uint32_t = 1) {}
 };
 template <>
 struct Tally<true> {
+  static constexpr bool on = true;
   uint32_t ev[RT_EV_COUNT];
   RT_DEV void clear() {
 #pragma unroll
@@ -158,8 +160,73 @@ RT_DEV V3 random_unit_vector(const Rng& g, uint32_t bounce, T& tally) {  // base
   return unit(random_in_unit_sphere(g, bounce, tally));
 }
 
-// ------------------------------------------------------------------------ scene context
+// The same draw for a whole wave at once: every lane with `need` gets what
+// random_in_unit_sphere(g, bounce) would return; ALL 64 lanes must call it, converged.
+// The plain loop runs until the unluckiest lane accepts (about four Philox blocks per wave and
+// bounce, against one needed per lane on average) with most lanes idle. Here every lane first
+// tries its own block 0; the lanes still without a vector (27 %) then publish their key in LDS and
+// the WHOLE wave works for them: lane l evaluates block next + (l mod h) of the (l / h)-th
+// unlucky lane, h = 16, 8, 4, 2 or 1 helpers each, so one more block time covers 2h further
+// candidates per unlucky lane. A ballot tells each unlucky lane which of its helpers accepted first
+// (helpers are in block order, the two candidates of a block in order: the reference's first
+// accepted draw) and it pulls that vector across lanes.
 #define RT_LDS __attribute__((address_space(3)))
+RT_DEV uint32_t wave_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+RT_DEV float lane_pull(float v, uint32_t src_lane) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
+}
+template <class T>
+RT_DEV V3 wave_random_in_unit_sphere(bool need, const Rng& g, uint32_t bounce, uint32_t RT_LDS* xch, T& tally) {
+  const uint32_t lane = wave_lane();
+  uint32_t o[4];
+  philox(g, 0, bounce, P_SPHERE, o);
+  V3 v0 = cube_point(o[0], o[1]), v1 = cube_point(o[2], o[3]);
+  bool ok0 = len2(v0) >= 1.0f, ok1 = len2(v1) >= 1.0f;
+  V3 v = ok0 ? v0 : v1;
+  bool found = !need || ok0 || ok1;
+  if (need) tally.template add<RT_EV_SPHERE_TRIAL>(ok0 ? 1 : 2);
+  uint32_t next_blk = 1;
+  unsigned long long unlucky = __ballot(!found);
+  while (unlucky != 0ull) {  // wave-uniform
+    const uint32_t n = (uint32_t)__popcll(unlucky);
+    const uint32_t k = n <= 4 ? 4u : n <= 8 ? 3u : n <= 16 ? 2u : n <= 32 ? 1u : 0u;  // log2(helpers each)
+    const uint32_t h = 1u << k;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(unlucky >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)unlucky, 0u));
+    if (!found) {
+      xch[rank * 4 + 0] = g.k0; xch[rank * 4 + 1] = g.k1; xch[rank * 4 + 2] = bounce; xch[rank * 4 + 3] = next_blk;
+    }
+    const uint32_t slot = lane >> k;
+    const bool helper = slot < n;
+    const uint32_t rs = helper ? slot : 0u;
+    Rng hg{xch[rs * 4 + 0], xch[rs * 4 + 1], g.s0, g.s1};
+    const uint32_t hb = xch[rs * 4 + 2];
+    const uint32_t blk = xch[rs * 4 + 3] + (lane & (h - 1u));
+    philox(hg, blk, hb, P_SPHERE, o);
+    v0 = cube_point(o[0], o[1]); v1 = cube_point(o[2], o[3]);
+    ok0 = len2(v0) >= 1.0f; ok1 = len2(v1) >= 1.0f;
+    const V3 hv = ok0 ? v0 : v1;
+    const unsigned long long accepted = __ballot(helper && (ok0 || ok1) && blk < RT_MAX_TRIALS / 2);
+    // this lane's helpers are lanes [rank * h, rank * h + h): the lowest set bit is the first accepted block
+    const uint32_t bits = (uint32_t)(accepted >> ((rank << k) & 63u)) & ((1u << h) - 1u);
+    const bool got = !found && bits != 0u;
+    const uint32_t first = (uint32_t)__builtin_ctz(bits | 0x10000u);
+    const uint32_t src = ((rank << k) + first) & 63u;
+    const float px = lane_pull(hv.x, src), py = lane_pull(hv.y, src), pz = lane_pull(hv.z, src);
+    if constexpr (T::on) {
+      const int first_cand = __builtin_amdgcn_ds_bpermute((int)(src << 2), ok0 ? 1 : 2);
+      if (!found) tally.template add<RT_EV_SPHERE_TRIAL>(got ? first * 2u + (uint32_t)first_cand : h * 2u);
+    }
+    if (got) { v = mk(px, py, pz); found = true; }
+    if (!found) {
+      next_blk += h;
+      if (next_blk >= RT_MAX_TRIALS / 2) found = true;  // give up like the plain loop (never in practice)
+    }
+    unlucky = __ballot(!found);
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------ scene context
 
 template <uint32_t FEAT>
 struct Ctx {
@@ -170,6 +237,7 @@ struct Ctx {
   const DChainRec RT_LDS* lds_chains;  // F_SMALL: its chain records in LDS
   const float* lds_perlin_vec;      // n_perlin * 1024 floats (LDS)
   const uint8_t* lds_perlin_perm;   // n_perlin * 768 bytes (LDS)
+  uint32_t RT_LDS* lds_xch;         // this wave's 1 KiB exchange area (wave_random_in_unit_sphere)
   int* lds_stack;                   // BVH stack base of this lane (stride = blockDim.x)
   int stack_stride;
 };
@@ -896,15 +964,20 @@ RT_DEV float reflectance(float cosine, float ref_idx) {  // base.clj:215-220
 
 // (scatter mat r rec) and (emitted mat u v p) of materials.clj. Returns ok; on ok the ray is
 // replaced by the scattered ray. `emitted` is only meaningful when !ok (core.clj:26-29).
-template <class X, class T>
-RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t bounce, V3& attenuation,
+RT_DEV bool needs_sphere_draw(int mtype) {
+  return mtype == RT_MAT_LAMBERTIAN || mtype == RT_MAT_METAL || mtype == RT_MAT_ISOTROPIC;
+}
+// With PRE, `sv` is random-in-unit-sphere for this bounce, drawn by the caller when
+// needs_sphere_draw(mtype); without it the material draws its own.
+template <bool PRE, class X, class T>
+RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t bounce, V3 sv, V3& attenuation,
                     V3& emitted, T& tally) {
   const int type = rec.mtype, flags = rec.mflags, tex = rec.mtex;
   const V3 rgb = rec.rgb;
   emitted = mk(0.f, 0.f, 0.f);
   if (type == RT_MAT_LAMBERTIAN) {  // :16-23
     tally.template add<RT_EV_LAMBERT>();
-    V3 dir = rec.n + random_unit_vector(g, bounce, tally);
+    V3 dir = rec.n + unit(PRE ? sv : random_in_unit_sphere(g, bounce, tally));  // random-unit-vector, base.clj:196-197
     attenuation = material_colour(ctx, flags, tex, rgb, rec, tally);
     r.o = rec.p; r.d = dir;
     return true;
@@ -919,7 +992,7 @@ RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t
     if (type == RT_MAT_METAL) {  // :33-39
       tally.template add<RT_EV_METAL>();
       V3 reflected = reflect(unit(r.d), rec.n);
-      V3 dir = madd(random_in_unit_sphere(g, bounce, tally), rec.mx, reflected);
+      V3 dir = madd(PRE ? sv : random_in_unit_sphere(g, bounce, tally), rec.mx, reflected);
       attenuation = rgb;
       r.o = rec.p; r.d = dir;
       return dot(dir, rec.n) > 0.0f;
@@ -946,7 +1019,7 @@ RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t
   if constexpr (X::has(F_MEDIA)) {
     if (type == RT_MAT_ISOTROPIC) {  // :87-90 — direction not normalised
       tally.template add<RT_EV_ISOTROPIC>();
-      V3 dir = random_in_unit_sphere(g, bounce, tally);
+      V3 dir = PRE ? sv : random_in_unit_sphere(g, bounce, tally);
       attenuation = material_colour(ctx, flags, tex, rgb, rec, tally);
       r.o = rec.p; r.d = dir;
       return true;

@@ -25,6 +25,7 @@ namespace rt {
 //   [0, n_perlin*4096)                 Perlin gradient vectors, float4 each
 //   [.., + n_perlin*768 rounded to 16) Perlin permutations, bytes
 //   [.., + n_prims*96 + n_chains*80)   DPrimInfo and DChainRec tables (F_SMALL instantiations only)
+//   [.., + blockDim/64 * 1024)         one exchange area per wave (wave_random_in_unit_sphere)
 //   [.., + blockDim*bvh_stack*4)       per-lane BVH stacks, entry e of lane l at e*blockDim + l
 template <uint32_t FEAT>
 __device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* lds) {
@@ -58,7 +59,9 @@ __device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* ld
   if constexpr ((FEAT & (F_NOISE | F_SMALL)) != 0) __syncthreads();
   X.lds_perlin_vec = reinterpret_cast<const float*>(lv);
   X.lds_perlin_perm = lp;
-  X.lds_stack = reinterpret_cast<int*>(lds + vec_bytes + perm_bytes + info_bytes) + threadIdx.x;
+  X.lds_xch = (uint32_t RT_LDS*)(lds + vec_bytes + perm_bytes + info_bytes) + (threadIdx.x >> 6) * 256;
+  const size_t xch_bytes = (size_t)(blockDim.x >> 6) * 1024;
+  X.lds_stack = reinterpret_cast<int*>(lds + vec_bytes + perm_bytes + info_bytes + xch_bytes) + threadIdx.x;
   X.stack_stride = blockDim.x;
   return X;
 }
@@ -85,22 +88,19 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 #define RT_STAMP(var)
 #endif
 
-template <class XC, class T>
-__device__ __forceinline__ bool path_step(const XC& X, const DRender& R, Ray& ray, V3& beta, uint32_t& bounce,
-                                          const Rng& g, V3& L, T& tally, unsigned long long* stamp_mid = nullptr,
-                                          unsigned long long* stamp_inner = nullptr) {
-  Rec rec;
-  bool hit = closest_hit(X, ray, 0.001f, __builtin_inff(), g, bounce, nullptr, false, false, rec, tally, stamp_inner);
-#ifdef RT_STAMPS
-  if (stamp_mid) RT_STAMP(*stamp_mid);
-#endif
+// The part of ray-color after the `hit` call (core.clj:24-30): `sv` is this bounce's
+// random-in-unit-sphere vector when the material draws one. Returns true when the path ended;
+// `L` is then the radiance of the whole path (throughput already applied).
+template <bool PRE, class XC, class T>
+__device__ __forceinline__ bool path_finish(const XC& X, const DRender& R, bool hit, const Rec& rec, V3 sv, Ray& ray,
+                                            V3& beta, uint32_t& bounce, const Rng& g, V3& L, T& tally) {
   if (!hit) {
     L = beta * mk(R.bg[0], R.bg[1], R.bg[2]);  // core.clj:30
     tally.template add<RT_EV_THROUGHPUT>();
     return true;
   }
   V3 attenuation, emitted;
-  if (scatter(X, rec, ray, g, bounce, attenuation, emitted, tally)) {
+  if (scatter<PRE>(X, rec, ray, g, bounce, sv, attenuation, emitted, tally)) {
     beta = beta * attenuation;  // core.clj:27
     tally.template add<RT_EV_THROUGHPUT>();
     ++bounce;
@@ -115,6 +115,16 @@ __device__ __forceinline__ bool path_step(const XC& X, const DRender& R, Ray& ra
   return true;
 }
 
+// One whole ray-color invocation for a lane on its own: the material draws its sphere vector with
+// the plain rejection loop.
+template <class XC, class T>
+__device__ __forceinline__ bool path_step(const XC& X, const DRender& R, Ray& ray, V3& beta, uint32_t& bounce,
+                                          const Rng& g, V3& L, T& tally) {
+  Rec rec;
+  const bool hit = closest_hit(X, ray, 0.001f, __builtin_inff(), g, bounce, nullptr, false, false, rec, tally);
+  return path_finish<false>(X, R, hit, rec, mk(0.f, 0.f, 0.f), ray, beta, bounce, g, L, tally);
+}
+
 // Waves per SIMD each instantiation is compiled for (the register allocator otherwise spreads over
 // the whole file): the lean instantiations are latency-bound on scalar loads and the RNG's
 // integer multiplies, which more resident waves hide.
@@ -123,6 +133,8 @@ constexpr int waves_per_simd(uint32_t feat, bool count) {
   // walks gain more from a third and fourth wave than the texture worlds lose
   if (feat & F_NOISE) return count ? 2 : ((feat & F_DEEP) ? 4 : 3);
   if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : 5;
+  // the smoke worlds' kernel spills at 72 registers once the wave-wide sphere draw is in: six waves measured 4 % faster
+  if (feat & F_MEDIA) return count ? 4 : 6;
   return count ? 4 : RT_WAVES_LEAN;
 }
 
@@ -155,7 +167,6 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
   Tally<COUNT> tally;
   if constexpr (COUNT) tally.clear();
 
-  const uint32_t lane = threadIdx.x & 63u;
   const int npix = R.width * R.height;
 
   // wave-uniform queue window [q_next, q_end) of work items taken from the global queue
@@ -165,14 +176,16 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
 
   // lane state
   bool have_item = false, active = false, done = false;
-  int px = 0, py = 0, pix = 0, chunk_id = 0;
-  int s = 0, s_end = 0;
+  // (the pixel index lives in g.k0 and the current sample index in g.k1: the keys of the path's
+  // random stream are the item's bookkeeping)
+  int px = 0, py = 0, chunk_id = 0;
+  uint32_t k1_end = 0;  // g.k1 of the sample after the item's last
   V3 acc = mk(0.f, 0.f, 0.f);
   Ray ray{mk(0, 0, 0), mk(0, 0, 1), 0.f};
   V3 beta = mk(1.f, 1.f, 1.f);
   uint32_t bounce = 0;
   Rng g{0u, 0u, R.seed_lo, R.seed_hi};
-  uint32_t n_rays = 0, n_samples = 0;
+  unsigned long long n_rays = 0, n_samples = 0;  // of the whole wave (wave-uniform, scalar registers)
   // HW_ID.wave_id (s_getreg id 4, offset 0, 4 bits): the wave's slot in its SIMD
   uint32_t prio_tick = __builtin_amdgcn_s_getreg(6148);
 
@@ -193,10 +206,10 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       default: __builtin_amdgcn_s_setprio(3); break;
     }
     RT_STAMP(ts0);
-    bool need = !active && !done && !(have_item && s < s_end);
+    bool need = !active && !done && !(have_item && g.k1 + 1u != k1_end);
     if (need && have_item) {
       // core.clj:115-120 finished for this chunk: store the partial sum of its samples
-      size_t o = ((size_t)chunk_id * npix + pix) * 3;
+      size_t o = ((size_t)chunk_id * npix + g.k0) * 3;
       out[o] = acc.x; out[o + 1] = acc.y; out[o + 2] = acc.z;
       have_item = false;
     }
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
         // multiple of 64), so the item is decoded once per window on wave-uniform values and a
         // lane only adds its place in the tile.
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(C->queue, 64u);
+        if (wave_lane() == 0) base = atomicAdd(C->queue, 64u);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= (uint32_t)C->R.n_items) {
           q_dry = true;
@@ -236,10 +249,10 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
           px = q_tx0 + (in_tile & 7);
           py = q_ty0 + (in_tile >> 3);
           if (px < R.width && py < R.height) {
-            pix = py * R.width + px;
+            g.k0 = (uint32_t)(py * R.width + px);
             chunk_id = q_chunk;
-            s = q_s0;
-            s_end = q_s1;
+            g.k1 = (uint32_t)(R.sample_offset + q_s0) - 1u;
+            k1_end = (uint32_t)(R.sample_offset + q_s1);
             acc = mk(0.f, 0.f, 0.f);
             have_item = true;
           }
@@ -250,12 +263,11 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       q_next += min(cnt, avail);
     }
     RT_STAMP(ts1);
-    if (!active && have_item && s < s_end) {
-      // core.clj:96-105: a fresh camera path for sample s of this pixel
-      g.k0 = (uint32_t)pix;
-      g.k1 = (uint32_t)(R.sample_offset + s);
-      ++s;
-      ++n_samples;
+    const bool fresh = !active && have_item && g.k1 + 1u != k1_end;
+    n_samples += (unsigned long long)__popcll(__ballot(fresh));
+    if (fresh) {
+      // core.clj:96-105: a fresh camera path for the item's next sample of this pixel
+      g.k1 += 1u;
       if (R.max_depth <= 0) {
         tally.template add<RT_EV_ACCUMULATE>();
       } else {
@@ -273,17 +285,42 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
 #ifdef RT_STAMPS
     ts3 = ts2; tsi = ts2;
 #endif
-    if (active) {
-      V3 L;
-      ++n_rays;
+    if constexpr ((FEAT & F_SMALL) != 0) {
+      // core.clj:23: the closest hit, for the lanes that carry a path
+      Rec rec;
+      rec.mtype = -1;
+      bool hit = false;
+      n_rays += (unsigned long long)__popcll(__ballot(active));
+      if (active) {
 #ifdef RT_STAMPS
-      if (path_step(X, R, ray, beta, bounce, g, L, tally, &ts3, &tsi)) {
+        hit = closest_hit(X, ray, 0.001f, __builtin_inff(), g, bounce, nullptr, false, false, rec, tally, &tsi);
 #else
-      if (path_step(X, R, ray, beta, bounce, g, L, tally)) {
+        hit = closest_hit(X, ray, 0.001f, __builtin_inff(), g, bounce, nullptr, false, false, rec, tally);
 #endif
-        acc = acc + L;  // core.clj:120
-        tally.template add<RT_EV_ACCUMULATE>();
-        active = false;
+      }
+      RT_STAMP(ts3);
+      // The bounce's random-in-unit-sphere vectors, drawn by the whole wave together. (Drawing
+      // before the hit record is built, while fewer registers are live, measured slower.)
+      const V3 sv = wave_random_in_unit_sphere(active && hit && needs_sphere_draw(rec.mtype), g, bounce, X.lds_xch, tally);
+      if (active) {
+        V3 L;
+        if (path_finish<true>(X, R, hit, rec, sv, ray, beta, bounce, g, L, tally)) {
+          acc = acc + L;  // core.clj:120
+          tally.template add<RT_EV_ACCUMULATE>();
+          active = false;
+        }
+      }
+    } else {
+      // The instantiations that walk a BVH lose more to the extra live state than the shared draw
+      // saves: there each lane runs ray-color on its own.
+      n_rays += (unsigned long long)__popcll(__ballot(active));
+      if (active) {
+        V3 L;
+        if (path_step(X, R, ray, beta, bounce, g, L, tally)) {
+          acc = acc + L;  // core.clj:120
+          tally.template add<RT_EV_ACCUMULATE>();
+          active = false;
+        }
       }
     }
 #ifdef RT_STAMPS
@@ -291,6 +328,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
     c_queue += ts1 - ts0; c_cam += ts2 - ts1; c_hit += ts3 - ts2; c_shade += ts4 - ts3; c_iters += 1; c_groups += tsi - ts2;
 #endif
   }
+  const uint32_t lane = wave_lane();
 #ifdef RT_STAMPS
   if (lane == 0) {
     atomicAdd(&stats[2 + 0], c_queue); atomicAdd(&stats[2 + 1], c_cam); atomicAdd(&stats[2 + 2], c_hit);
@@ -302,10 +340,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
 #endif
   // One atomic per wave and counter, not per lane: half a million same-address atomics at the end
   // of the kernel serialise in L2 and cost milliseconds.
-  {
-    unsigned long long ws = wave_sum(n_samples), wr = wave_sum(n_rays);
-    if (lane == 0) { atomicAdd(&stats[0], ws); atomicAdd(&stats[1], wr); }
-  }
+  if (lane == 0) { atomicAdd(&stats[0], n_samples); atomicAdd(&stats[1], n_rays); }
   if constexpr (COUNT) {
 #pragma unroll
     for (int e = 0; e < RT_EV_COUNT; ++e) {
@@ -417,7 +452,7 @@ size_t shade_lds_bytes(const DScene& S, int block) {
   size_t vec_bytes = (size_t)S.n_perlin * 4096;
   size_t perm_bytes = ((size_t)S.n_perlin * 768 + 15) & ~(size_t)15;
   size_t info_bytes = pick_variant(S) < 2 ? (size_t)S.n_prims * sizeof(DPrimInfo) + (size_t)S.n_chains * sizeof(DChainRec) : 0;
-  return vec_bytes + perm_bytes + info_bytes + (size_t)block * (size_t)S.bvh_stack * 4;
+  return vec_bytes + perm_bytes + info_bytes + (size_t)(block / 64) * 1024 + (size_t)block * (size_t)S.bvh_stack * 4;
 }
 
 template <class F>
