@@ -163,6 +163,27 @@ def test_render_same_random_stream(gpu_ctx, oracle, name):
     sc.close()
 
 
+@pytest.mark.parametrize("name", ["cornell-box", "cornell-smoke", "two-spheres", "final-scene"])
+def test_render_is_the_sum_of_its_samples_bit_for_bit(gpu_ctx, name):
+    """The render loop (wave-wide sphere draw in the small-scene kernels, lanes refilled in place)
+    against rt_sample_batch (one lane per sample, per-lane rejection loop): draws are addressed by
+    (pixel, sample, bounce, purpose), so both must produce the same FP32 radiance for every sample,
+    and with one sample per chunk the frame is their sum in sample order."""
+    cfg, flat, cam = scene_bundle(name)
+    sc = gpu_ctx.scene(flat)
+    W, H, spp = 29, 19, 5
+    p = abi.make_params(W, H, spp, 50, cfg["background"], seed=77)
+    rgb, argb, st = sc.render(cam, p)
+    px = np.repeat(np.arange(W * H, dtype=np.int32), spp)
+    smp = np.tile(np.arange(spp, dtype=np.int32), W * H)
+    rad = sc.sample_batch(cam, p, px, smp).reshape(H, W, spp, 3).astype(np.float32)
+    acc = np.zeros((H, W, 3), np.float32)
+    for k in range(spp):
+        acc = acc + rad[:, :, k, :]
+    assert np.array_equal(acc.view(np.uint32), rgb.astype(np.float32).view(np.uint32))
+    sc.close()
+
+
 def test_tonemap_is_bit_exact(gpu_ctx, oracle):
     """core.clj:106-108 + Color(float,float,float): the packed pixel is a pure function of the FP32
     sums, so device and oracle must agree bit for bit given the device's own sums."""
