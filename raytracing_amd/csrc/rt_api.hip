@@ -597,10 +597,35 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   for (auto& c : F.chains) {
     chains.push_back(DChain{(int)ops.size(), (int)c.size()});
     ops.insert(ops.end(), c.begin(), c.end());
+    // the record side, composed in FP64 from the innermost wrapper outwards (see DChainRec)
     DChainRec rec;
     std::memset(&rec, 0, sizeof rec);
     rec.n_ops = (int)c.size();
-    for (size_t i = 0; i < c.size(); ++i) { rec.ops[i].kind = c[i].kind; rec.ops[i].a = c[i].a; rec.ops[i].b = c[i].b; rec.ops[i].c = c[i].c; }
+    rec.inner = c.size() >= 2 ? 1 : 0;
+    double A = 1.0, B = 0.0, t[3] = {0.0, 0.0, 0.0};
+    rec.A1 = 1.f; rec.B1 = 0.f;
+    for (size_t i = c.size(); i-- > 0;) {
+      if (c[i].kind == DOP_TRANSLATE) {
+        t[0] += c[i].da; t[1] += c[i].db; t[2] += c[i].dc;
+      } else {
+        const double so = c[i].da, co = c[i].db;
+        const double nA = co * A + so * B, nB = co * B + so * A;
+        const double nx = co * t[0] + so * t[2], nz = so * t[0] + co * t[2];
+        A = nA; B = nB; t[0] = nx; t[2] = nz;
+        ++rec.n_rotate;
+      }
+      if (i == 1) { rec.A1 = (float)A; rec.B1 = (float)B; }  // everything but the outermost
+    }
+    rec.A = (float)A; rec.B = (float)B; rec.tx = (float)t[0]; rec.ty = (float)t[1]; rec.tz = (float)t[2];
+    // the ray side's turn (rotate.clj:14-24, angles add) after the outermost and after the two outermost
+    double s0 = 0.0, c0 = 1.0;
+    if (!c.empty() && c[0].kind == DOP_ROTATE_Y) { s0 = c[0].da; c0 = c[0].db; }
+    double s01 = s0, c01 = c0;
+    if (c.size() >= 2 && c[1].kind == DOP_ROTATE_Y) {
+      const double so = c[1].da, co = c[1].db;
+      c01 = co * c0 - so * s0; s01 = so * c0 + co * s0;
+    }
+    rec.s0 = (float)s0; rec.c0 = (float)c0; rec.s01 = (float)s01; rec.c01 = (float)c01;
     chain_recs.push_back(rec);
   }
 

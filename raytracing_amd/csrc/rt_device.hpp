@@ -665,46 +665,35 @@ RT_DEV void prim_record(const DScene& S, int prim, const DPrimInfo& I, const Ray
   }
 }
 
-// Record fix-ups on the way back up a chain: rotate.clj:31-47 (both components use +sin, and the
-// face test is against the ROTATED ray) then translate.clj:13-17 (face test against the moved
-// ray, whose direction is the outer one). CHAIN points at the chain's record (LDS for small
-// scenes); the chain differs per lane.
+// Record fix-ups on the way back up a chain, rotate.clj:31-47 and translate.clj:13-17 for every
+// wrapper at once (see DChainRec): the composed point map and the face tests of the two outermost
+// wrappers. CHAIN points at the chain's record (LDS for small scenes); the chain differs per lane.
+RT_DEV V3 turn_y(float s, float c, V3 d) {  // rotate.clj:14-24, the ray side
+  return mk(fmaf(c, d.x, -(s * d.z)), d.y, fmaf(s, d.x, c * d.z));
+}
+RT_DEV V3 map_rec(float A, float B, V3 n) {  // rotate.clj:32-42 composed, the record side
+  return mk(fmaf(A, n.x, B * n.z), n.y, fmaf(B, n.x, A * n.z));
+}
 template <class X, class CHAIN, class T>
 RT_DEV void chain_unwind_rec(CHAIN C, V3 world_d, Rec& rec, T& tally) {
   const int n_ops = C->n_ops;
   if (n_ops == 0) return;
-  int kind[RT_MAX_CHAIN_OPS];
-  float oa[RT_MAX_CHAIN_OPS], ob[RT_MAX_CHAIN_OPS], oc[RT_MAX_CHAIN_OPS];
-#pragma unroll
-  for (int i = 0; i < RT_MAX_CHAIN_OPS; ++i) { kind[i] = C->ops[i].kind; oa[i] = C->ops[i].a; ob[i] = C->ops[i].b; oc[i] = C->ops[i].c; }
-  V3 dirs[RT_MAX_CHAIN_OPS + 1];
-  dirs[0] = world_d;
-#pragma unroll
-  for (int i = 0; i < RT_MAX_CHAIN_OPS; ++i) {
-    V3 d = dirs[i];
-    if (i < n_ops && kind[i] == DOP_ROTATE_Y) d = mk(fmaf(ob[i], d.x, -(oa[i] * d.z)), d.y, fmaf(oa[i], d.x, ob[i] * d.z));
-    dirs[i + 1] = d;
+  if constexpr (T::on) {
+    const int n_rot = C->n_rotate;
+    tally.template add<RT_EV_ROTATE_REC>((uint32_t)n_rot);
+    tally.template add<RT_EV_TRANSLATE_REC>((uint32_t)(n_ops - n_rot));
   }
-#pragma unroll
-  for (int i = RT_MAX_CHAIN_OPS - 1; i >= 0; --i) {
-    if (i < n_ops) {
-      V3 d_inner = dirs[i + 1];
-      if (kind[i] == DOP_ROTATE_Y) {
-        float s = oa[i], c = ob[i];
-        V3 p = rec.p, n = rec.n;
-        rec.p = mk(fmaf(c, p.x, s * p.z), p.y, fmaf(s, p.x, c * p.z));
-        V3 nn = mk(fmaf(c, n.x, s * n.z), n.y, fmaf(s, n.x, c * n.z));
-        rec.front = dot(d_inner, nn) < 0.0f;
-        rec.n = rec.front ? nn : neg(nn);
-        tally.template add<RT_EV_ROTATE_REC>();
-      } else {
-        rec.front = dot(d_inner, rec.n) < 0.0f;
-        rec.n = rec.front ? rec.n : neg(rec.n);
-        rec.p = mk(rec.p.x + oa[i], rec.p.y + ob[i], rec.p.z + oc[i]);
-        tally.template add<RT_EV_TRANSLATE_REC>();
-      }
-    }
-  }
+  const float A = C->A, B = C->B, s0 = C->s0, c0 = C->c0;
+  const V3 p = rec.p;
+  rec.p = mk(fmaf(A, p.x, fmaf(B, p.z, C->tx)), p.y + C->ty, fmaf(B, p.x, fmaf(A, p.z, C->tz)));
+  // inside the outermost wrapper: the normal as the second-outermost wrapper oriented it
+  V3 n1 = map_rec(C->A1, C->B1, rec.n);
+  const bool keep = dot(turn_y(C->s01, C->c01, world_d), n1) < 0.0f || C->inner == 0;
+  n1 = keep ? n1 : neg(n1);
+  // the outermost wrapper
+  const V3 nn = map_rec(c0, s0, n1);
+  rec.front = dot(turn_y(s0, c0, world_d), nn) < 0.0f;
+  rec.n = rec.front ? nn : neg(nn);
 }
 
 template <class X, class T>

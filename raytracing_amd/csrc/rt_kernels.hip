@@ -24,7 +24,7 @@ namespace rt {
 // Dynamic LDS layout shared by all kernels that shade:
 //   [0, n_perlin*4096)                 Perlin gradient vectors, float4 each
 //   [.., + n_perlin*768 rounded to 16) Perlin permutations, bytes
-//   [.., + n_prims*96 + n_chains*80)   DPrimInfo and DChainRec tables (F_SMALL instantiations only)
+//   [.., + n_prims*96 + n_chains*64)   DPrimInfo and DChainRec tables (F_SMALL instantiations only)
 //   [.., + blockDim/64 * 1024)         one exchange area per wave (wave_random_in_unit_sphere)
 //   [.., + blockDim*bvh_stack*4)       per-lane BVH stacks, entry e of lane l at e*blockDim + l
 template <uint32_t FEAT>

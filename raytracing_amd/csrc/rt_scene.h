@@ -62,15 +62,26 @@ struct DChain {
   int32_t first_op, n_ops;
 };
 
-// 80 bytes: a whole chain (FP32 side) in one record, so the record fix-ups on the way back up
-// need one lookup. Staged in LDS for small scenes.
+// 64 bytes: the record side of a whole chain. On the way back up, every wrapper maps the hit
+// point (rotate.clj:32-36: x' = c x + s z, z' = s x + c z, both with +sin; translate.clj:16:
+// p + offset) and re-orients the normal against its own ray (rotate.clj:43, translate.clj:13).
+// The point maps compose into one, p' = [[A B] [B A]] (x z) + t. A wrapper's normal is
+// +-(its map)(inner normal) with the sign picked by ITS face test, whatever the wrappers inside
+// decided; front-face says whether that sign kept the inner wrapper's choice. So the outcome needs
+// two face tests only: the second-outermost wrapper's (map [[A1 B1] [B1 A1]] = all wrappers but
+// the outermost, against the world ray turned by (s01, c01) = the ray inside that wrapper), then
+// the outermost's (its own record map (s0, c0), against the world ray turned by (s0, c0); a
+// translate keeps the direction: (0, 1)). With a single wrapper the primitive's own orientation
+// stands in for the inner test (inner = 0).
+// Staged in LDS for small scenes.
 struct DChainRec {
-  int32_t n_ops;
-  int32_t pad[3];
-  struct Op {
-    int32_t kind;
-    float a, b, c;
-  } ops[RT_MAX_CHAIN_OPS];
+  int32_t n_ops;      // 0: identity chain, nothing to do
+  int32_t n_rotate;   // how many of the n_ops are rotate-y (event accounting)
+  int32_t inner;      // 1 when n_ops >= 2
+  int32_t pad0;
+  float A, B, tx, ty;
+  float tz, s0, c0, A1;
+  float B1, s01, c01, pad1;
 };
 #define RT_LDS_CHAINS 64  // F_SMALL instantiations keep up to this many chain records in LDS
 
