@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -725,7 +726,8 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   prims.resize(n_real_prims);
   S.prims = d_prims;
 
-  // BVHs for the large groups, built on the device
+  // BVHs for the large groups: surface-area trees from the host up to RT_SAH_MAX primitives, the
+  // device's Morton build beyond (or when RTMI_BVH_MORTON is set, to compare the two)
   int n_bvh_nodes = 0;
   auto group_size = [](const DGroup& G) { return G.n_xy + G.n_xz + G.n_yz + G.n_sph; };
   for (auto& G : groups)
@@ -743,7 +745,9 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
     const int n_prims = group_size(G);
     if (n_prims <= RT_BRUTE_MAX) continue;
     int height = 0;
-    hipError_t e = build_bvh(d_prims, G.first_prim, n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0);
+    hipError_t e = (n_prims <= RT_SAH_MAX && !std::getenv("RTMI_BVH_MORTON"))
+                       ? build_bvh_sah(prims.data(), G.first_prim, n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0)
+                       : build_bvh(d_prims, G.first_prim, n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e));
     G.bvh_root = node_base;
     node_base += n_prims - 1;

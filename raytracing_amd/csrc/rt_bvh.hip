@@ -9,6 +9,11 @@
 // cross-workgroup visibility a single-launch atomic scheme would have to fence for).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <vector>
+
 #include "rt_launch.h"
 
 namespace rt {
@@ -18,7 +23,7 @@ struct Box {
   float mn[3], mx[3];
 };
 
-__device__ __forceinline__ void prim_box(const DPrim& P, float time_lo, float time_hi, Box& b) {
+__host__ __device__ __forceinline__ void prim_box(const DPrim& P, float time_lo, float time_hi, Box& b) {
   const int type = P.type & 15;
   if (type == RT_PRIM_SPHERE || type == RT_PRIM_MOVING_SPHERE) {
     double r = fabs(type == RT_PRIM_SPHERE ? P.d[3] : P.d[8]);
@@ -250,6 +255,116 @@ hipError_t build_bvh(const DPrim* d_prims, int first, int n, DBvhNode* d_nodes, 
   BVH_CHECK(hipStreamSynchronize(stream));
   cleanup();
   return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host construction by the surface-area heuristic, for groups small enough that a top-down build
+// is instant. A ray's walk is as long as the boxes it pierces, and the Morton tree above ignores
+// box sizes altogether; every candidate plane between two centroids, on every axis, is priced as
+// area(left) * count(left) + area(right) * count(right) (exact sweep, one primitive per leaf).
+// Nodes are laid out in depth-first order: a node's left child is the next record.
+namespace {
+
+struct HBox {
+  float mn[3], mx[3];
+  void grow(const HBox& o) {
+    for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], o.mn[a]); mx[a] = std::max(mx[a], o.mx[a]); }
+  }
+  float half_area() const {
+    const float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
+    return x * y + y * z + z * x;
+  }
+  static HBox empty() { return HBox{{3.4e38f, 3.4e38f, 3.4e38f}, {-3.4e38f, -3.4e38f, -3.4e38f}}; }
+};
+
+struct SahBuilder {
+  const std::vector<HBox>& boxes;
+  int first, node_base;
+  std::vector<DBvhNode>& nodes;  // n - 1 records, appended in depth-first order
+  std::vector<int> idx, tmp;
+  std::vector<float> right_area;
+  int max_height = 0;
+
+  HBox bounds(int lo, int hi) const {
+    HBox b = HBox::empty();
+    for (int i = lo; i < hi; ++i) b.grow(boxes[idx[i]]);
+    return b;
+  }
+  float centroid(int i, int a) const { return 0.5f * (boxes[i].mn[a] + boxes[i].mx[a]); }
+
+  // Builds the subtree over idx[lo, hi) (hi - lo >= 2), returns its node index; depth = levels above.
+  int build(int lo, int hi, int depth) {
+    const int n = hi - lo;
+    const int me = (int)nodes.size();
+    nodes.push_back(DBvhNode{});
+    max_height = std::max(max_height, depth + 1);
+    int best_axis = -1, best_split = lo + n / 2;
+    float best_cost = 3.4e38f;
+    for (int a = 0; a < 3; ++a) {
+      std::sort(idx.begin() + lo, idx.begin() + hi, [&](int x, int y) {
+        const float cx = centroid(x, a), cy = centroid(y, a);
+        return cx < cy || (cx == cy && x < y);
+      });
+      HBox r = HBox::empty();
+      for (int i = hi - 1; i > lo; --i) { r.grow(boxes[idx[i]]); right_area[i] = r.half_area(); }
+      HBox l = HBox::empty();
+      for (int i = lo + 1; i < hi; ++i) {  // left = [lo, i), right = [i, hi)
+        l.grow(boxes[idx[i - 1]]);
+        const float cost = l.half_area() * (float)(i - lo) + right_area[i] * (float)(hi - i);
+        if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = i; }
+      }
+    }
+    if (best_axis != 2) {  // idx is sorted along axis 2 now: redo the winner's order
+      const int a = best_axis < 0 ? 0 : best_axis;
+      std::sort(idx.begin() + lo, idx.begin() + hi, [&](int x, int y) {
+        const float cx = centroid(x, a), cy = centroid(y, a);
+        return cx < cy || (cx == cy && x < y);
+      });
+    }
+    // Past 28 levels the rest is split in halves: the per-lane stack (LDS) is sized by the height.
+    const int mid = depth >= 28 ? lo + n / 2 : best_split;
+    const HBox lb = bounds(lo, mid), rb = bounds(mid, hi);
+    const int left = (mid - lo == 1) ? ~(first + idx[lo]) : build(lo, mid, depth + 1);
+    const int right = (hi - mid == 1) ? ~(first + idx[mid]) : build(mid, hi, depth + 1);
+    DBvhNode& N = nodes[me];
+    for (int a = 0; a < 3; ++a) { N.lmin[a] = lb.mn[a]; N.lmax[a] = lb.mx[a]; N.rmin[a] = rb.mn[a]; N.rmax[a] = rb.mx[a]; }
+    N.left = left < 0 ? left : node_base + left;
+    N.right = right < 0 ? right : node_base + right;
+    N.pad[0] = N.pad[1] = 0;
+    return me;
+  }
+};
+
+}  // namespace
+
+hipError_t build_bvh_sah(const DPrim* h_prims, int first, int n, DBvhNode* d_nodes, int node_base, float time_lo,
+                         float time_hi, int* height_out, hipStream_t stream) {
+  if (n < 2) return hipErrorInvalidValue;
+  std::vector<HBox> boxes((size_t)n);
+  float ext = 0.f;
+  for (int i = 0; i < n; ++i) {
+    Box b;
+    prim_box(h_prims[first + i], time_lo, time_hi, b);
+    for (int a = 0; a < 3; ++a) {
+      boxes[i].mn[a] = b.mn[a]; boxes[i].mx[a] = b.mx[a];
+      ext = std::max(ext, std::max(std::fabs(b.mn[a]), std::fabs(b.mx[a])));
+    }
+  }
+  const float pad = ext * 3.814697265625e-6f + 1e-30f;  // as k_pad_boxes
+  for (auto& b : boxes)
+    for (int a = 0; a < 3; ++a) { b.mn[a] -= pad; b.mx[a] += pad; }
+  std::vector<DBvhNode> nodes;
+  nodes.reserve((size_t)n - 1);
+  SahBuilder B{boxes, first, node_base, nodes, {}, {}, {}, 0};
+  B.idx.resize((size_t)n);
+  std::iota(B.idx.begin(), B.idx.end(), 0);
+  B.right_area.resize((size_t)n + 1);
+  B.build(0, n, 0);
+  if ((int)nodes.size() != n - 1) return hipErrorUnknown;
+  *height_out = B.max_height;
+  hipError_t e = hipMemcpyAsync(d_nodes + node_base, nodes.data(), sizeof(DBvhNode) * nodes.size(), hipMemcpyHostToDevice, stream);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(stream);
 }
 
 }  // namespace rt
