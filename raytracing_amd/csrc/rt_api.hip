@@ -435,6 +435,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   uint32_t features = 0;  // F_* mask
   std::vector<DGroup64> groups64;
   std::vector<float> brute_rects;
+  std::vector<float> brute_boxes;
   // the chain's ray side collapsed to one rigid motion about y: o' = Ry(o) + b (see DGroup)
   auto chain_motion = [&](int chain, DGroup& G, DGroup64& H) {
     double c = 1.0, s = 0.0, b[3] = {0.0, 0.0, 0.0};
@@ -538,14 +539,61 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
         prims.push_back(P);
       }
       G.first_rect = (int)(brute_rects.size() / RT_PAIR_STRIDE);
+      G.first_box = (int)(brute_boxes.size() / RT_BOX_STRIDE);
       if ((int)list.size() <= RT_BRUTE_MAX) {
-        // pair records per orientation (see DScene.brute_rects)
-        int off = G.first_prim;
+        // Six rects that close an axis-aligned box with one material (what box.clj:7-20 builds) are
+        // intersected as one slab test; they keep their primitive records and indices.
+        const int o_xy = G.first_prim, o_xz = o_xy + G.n_xy, o_yz = o_xz + G.n_xz, o_end = o_yz + G.n_yz;
+        std::vector<char> boxed((size_t)(o_end - G.first_prim), 0);
+        auto F5 = [&](int i) { return prims[(size_t)i].f; };  // a0 a1 b0 b1 k
+        auto used = [&](int i) -> char& { return boxed[(size_t)(i - G.first_prim)]; };
+        auto same_face = [&](int i, int j) {
+          const float *a = F5(i), *b = F5(j);
+          return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3] && prims[(size_t)i].mat == prims[(size_t)j].mat;
+        };
+        int n_box = 0;
+        for (int p = o_xy; p < o_xz; ++p) {
+          for (int q = p + 1; q < o_xz && !used(p); ++q) {
+            if (used(q) || !same_face(p, q) || F5(p)[4] == F5(q)[4]) continue;
+            const float x0 = F5(p)[0], x1 = F5(p)[1], y0 = F5(p)[2], y1 = F5(p)[3];
+            const float z0 = std::min(F5(p)[4], F5(q)[4]), z1 = std::max(F5(p)[4], F5(q)[4]);
+            if (!(x0 < x1 && y0 < y1)) continue;
+            // the XZ pair at y0, y1 over [x0,x1] x [z0,z1] and the YZ pair at x0, x1 over [y0,y1] x [z0,z1]
+            auto find_pair = [&](int lo, int hi, float a0, float a1, float b0, float b1, float k0, float k1, int out[2]) {
+              out[0] = out[1] = -1;
+              for (int i = lo; i < hi; ++i) {
+                if (used(i) || prims[(size_t)i].mat != prims[(size_t)p].mat) continue;
+                const float* f = F5(i);
+                if (f[0] != a0 || f[1] != a1 || f[2] != b0 || f[3] != b1) continue;
+                if (f[4] == k0 && out[0] < 0) out[0] = i;
+                else if (f[4] == k1 && out[1] < 0) out[1] = i;
+              }
+              return out[0] >= 0 && out[1] >= 0;
+            };
+            int fy[2], fx[2];
+            if (!find_pair(o_xz, o_yz, x0, x1, z0, z1, y0, y1, fy)) continue;
+            if (!find_pair(o_yz, o_end, y0, y1, z0, z1, x0, x1, fx)) continue;
+            const int fz[2] = {F5(p)[4] == z0 ? p : q, F5(p)[4] == z0 ? q : p};
+            for (float v : {x0, x1, y0, y1, z0, z1}) brute_boxes.push_back(v);
+            for (int i : {fz[0], fz[1], fy[0], fy[1], fx[0], fx[1]}) {
+              float bits;
+              std::memcpy(&bits, &i, 4);
+              brute_boxes.push_back(bits);
+              used(i) = 1;
+            }
+            ++n_box;
+          }
+        }
+        // pair records per orientation (see DScene.brute_rects) for the rects no box took
+        int off = G.first_prim, loose_n[3] = {0, 0, 0}, ti = 0;
         for (int n_t : {G.n_xy, G.n_xz, G.n_yz}) {
-          const int odd = n_t & 1;
-          for (int p = 0; p < (n_t + 1) / 2; ++p) {
-            const int i1 = off + 2 * p + 1 - odd;
-            const int i0 = std::max(i1 - 1, off);
+          std::vector<int> loose;
+          for (int i = off; i < off + n_t; ++i)
+            if (!used(i)) loose.push_back(i);
+          const int n_l = (int)loose.size(), odd = n_l & 1;
+          for (int p = 0; p < (n_l + 1) / 2; ++p) {
+            const int j1 = 2 * p + 1 - odd;
+            const int i1 = loose[(size_t)j1], i0 = loose[(size_t)std::max(j1 - 1, 0)];
             const float* f0 = prims[(size_t)i0].f;
             const float* f1 = prims[(size_t)i1].f;
             // DPrim.f = a0 a1 b0 b1 k
@@ -556,8 +604,10 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
             brute_rects.push_back(bits[0]);
             brute_rects.push_back(bits[1]);
           }
+          loose_n[ti++] = n_l;
           off += n_t;
         }
+        G.loose = loose_n[0] | (loose_n[1] << 8) | (loose_n[2] << 16) | (n_box << 24);
       }
       groups.push_back(G);
       groups64.push_back(H);
@@ -762,6 +812,8 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
 
   brute_rects.resize(brute_rects.size() + RT_PAIR_STRIDE * RT_PAIR_BATCH, 0.f);  // slack for batched reads
   if ((rc = upload(sc, brute_rects, &S.brute_rects))) return rc;
+  brute_boxes.resize(brute_boxes.size() + RT_BOX_STRIDE, 0.f);  // slack
+  if ((rc = upload(sc, brute_boxes, &S.brute_boxes))) return rc;
   if ((rc = upload(sc, infos, &S.prim_info))) return rc;
   S.n_prims = (int)prims.size();
   if ((rc = upload(sc, groups, &S.groups))) return rc;

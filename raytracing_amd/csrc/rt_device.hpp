@@ -551,6 +551,52 @@ RT_DEV void brute_rects(const float RT_CONST* R, int n_xy, int n_xz, int n_yz, c
   }
 }
 
+// The six rects of a closed box (box.clj:7-20) as one slab test. Each face is a plane hit at
+// t = (k - o) / d that lies inside the face exactly when t is inside the slabs of the other two
+// axes, so the faces the reference's scan accepts are the entry point max(near) and the exit point
+// min(far) whenever max(near) <= min(far), and its closest-so-far rule keeps the first of them that
+// is >= t-min. t is computed as the rect test computes it; the in-face test is made on parameters
+// instead of points, which differs only where a ray grazes an edge within rounding. Where two
+// faces tie (an edge), the later one in scan order (XY, XZ, YZ faces) wins, as `<=` makes it in
+// the scan.
+template <class T>
+RT_DEV void brute_boxes(const float RT_CONST* B, int n_box, const RayX& r, float tmin, Best& best, T& tally) {
+  const f2 ox = {r.o.x, r.o.x}, oy = {r.o.y, r.o.y}, oz = {r.o.z, r.o.z};
+  const f2 ix = {r.inv.x, r.inv.x}, iy = {r.inv.y, r.inv.y}, iz = {r.inv.z, r.inv.z};
+  for (int b = 0; b < n_box; ++b) {
+    float w[RT_BOX_STRIDE];
+#pragma unroll
+    for (int q = 0; q < RT_BOX_STRIDE; ++q) w[q] = B[b * RT_BOX_STRIDE + q];
+    // the whole record in SGPRs before any of it is used: one scalar-memory round trip per box
+    asm volatile("" ::"s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]), "s"(w[4]), "s"(w[5]), "s"(w[6]), "s"(w[7]), "s"(w[8]),
+                 "s"(w[9]), "s"(w[10]), "s"(w[11]));
+    tally.template add<RT_EV_RECT_TEST>(6);
+    const f2 tx = ((f2){w[0], w[1]} - ox) * ix;
+    const f2 ty = ((f2){w[2], w[3]} - oy) * iy;
+    const f2 tz = ((f2){w[4], w[5]} - oz) * iz;
+    // fminf/fmaxf drop a NaN operand (0 * inf when the origin lies on a face's plane)
+    const float nx = fminf(tx.x, tx.y), fx = fmaxf(tx.x, tx.y);
+    const float ny = fminf(ty.x, ty.y), fy = fmaxf(ty.x, ty.y);
+    const float nz = fminf(tz.x, tz.y), fz = fmaxf(tz.x, tz.y);
+    const float tn = fmaxf(fmaxf(nx, ny), nz), tf = fminf(fminf(fx, fy), fz);
+    const float t = tn >= tmin ? tn : tf;
+    // accepted iff tn <= tf, t >= t-min and t <= closest-so-far: the OR of the three differences'
+    // sign bits, as in rect_pair (x - x is +0, so every equality accepts)
+    const int sgn = __float_as_int(tf - tn) | __float_as_int(t - tmin) | __float_as_int(best.t - t);
+    const bool ok = sgn >= 0;
+    // the face whose plane gave t; where two planes tie (an edge) the later one in scan order
+    // (z0 z1 y0 y1 x0 x1) wins, as the scan's `<=` makes it
+    int face = __float_as_int(w[6]);
+    face = tz.y == t ? __float_as_int(w[7]) : face;
+    face = ty.x == t ? __float_as_int(w[8]) : face;
+    face = ty.y == t ? __float_as_int(w[9]) : face;
+    face = tx.x == t ? __float_as_int(w[10]) : face;
+    face = tx.y == t ? __float_as_int(w[11]) : face;
+    best.t = ok ? t : best.t;
+    best.prim = ok ? face : best.prim;
+  }
+}
+
 // Closest hit of group g for the world ray wr with t in (tmin, best.t].
 template <class X, class T>
 RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best, T& tally) {
@@ -563,9 +609,11 @@ RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best
   } else {
     const DPrim RT_CONST* prims = cptr(S.prims);
     int first = G.first_prim;
-    const int n_xy = G.n_xy, n_xz = G.n_xz, n_yz = G.n_yz;
-    brute_rects(cptr(S.brute_rects) + G.first_rect * RT_PAIR_STRIDE, n_xy, n_xz, n_yz, r, tmin, best, tally);
-    first += n_xy + n_xz + n_yz;
+    const int loose = G.loose;
+    brute_rects(cptr(S.brute_rects) + G.first_rect * RT_PAIR_STRIDE, loose & 255, (loose >> 8) & 255, (loose >> 16) & 255,
+                r, tmin, best, tally);
+    brute_boxes(cptr(S.brute_boxes) + G.first_box * RT_BOX_STRIDE, loose >> 24, r, tmin, best, tally);
+    first += G.n_xy + G.n_xz + G.n_yz;
     if constexpr (X::has(F_SPHERES)) {
       const int n_sph = G.n_sph;
       for (int i = 0; i < n_sph; ++i) {

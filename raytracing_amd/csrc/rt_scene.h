@@ -22,6 +22,7 @@
 #define RT_MAX_CHUNKS 128      // work items per pixel, at most
 #define RT_TILE 8              // pixels per tile edge; one wave64 = one 8x8 tile
 #define RT_PAIR_STRIDE 12      // dwords per pair record of DScene.brute_rects
+#define RT_BOX_STRIDE 12       // dwords per box record of DScene.brute_boxes
 #define RT_PAIR_BATCH 3        // pair records the brute-force loop fetches per scalar-memory round trip
 
 enum { DOP_TRANSLATE = 0, DOP_ROTATE_Y = 1 };
@@ -100,7 +101,11 @@ struct DGroup {
   // rotate.clj:18-27 compose exactly): o' = Ry(o) + b, d' = Ry(d), Ry(v) = [c vx - s vz, vy, s vx + c vz].
   // Only the ray side may be collapsed; records go back up the chain operation by operation.
   float rc, rs, bx, by, bz;
-  int32_t pad[2];
+  // Brute-force groups: six rects that close an axis-aligned box (box.clj:7-20) are intersected as
+  // ONE slab test (DScene.brute_boxes) and left out of the pair records. `loose` packs what the
+  // pair records still hold and the number of boxes: xy | xz << 8 | yz << 16 | boxes << 24.
+  int32_t loose;
+  int32_t first_box;
 };
 struct DGroup64 {  // the same motion in FP64, for DGROUP_SPHERES_UNDER_CHAIN groups
   double rc, rs, bx, by, bz;
@@ -173,6 +178,9 @@ struct DScene {
                                  // pairs, YZ pairs. A run of odd length starts with a pair whose first slot
                                  // repeats its second (same index): the repeat is tested first and the real
                                  // rect, accepting a tie, overwrites it. RT_PAIR_BATCH records of slack follow.
+  const float* brute_boxes;      // the closed boxes of the brute-force groups: x0 x1 y0 y1 z0 z1, then the device
+                                 // primitive indices (int bits) of the faces z = z0, z = z1, y = y0, y = y1,
+                                 // x = x0, x = x1. One record of slack follows.
   const DPrimInfo* prim_info;
   const DGroup* groups;
   const DGroup64* groups64;
