@@ -1,0 +1,99 @@
+"""Boxes (box.clj:7-20) on the device are one slab test instead of six rect tests. These tests
+aim at where the two formulations could part: rays that start inside a box or on a face, rays
+along the axes, rays through edges and corners (exact ties between faces), boxes sharing a group
+with loose rects, and six rects that only look like a box (two materials: not merged)."""
+import numpy as np
+import pytest
+
+from raytracing_amd import flatten
+from raytracing_amd.hittables import (box, constant_medium, hittable_list, rotate_y, translate, xy_rect, xz_rect,
+                                      yz_rect)
+from raytracing_amd.materials import lambertian
+from test_gpu_parity import _check_hits
+
+pytestmark = pytest.mark.gpu
+RED, GREEN, WHITE = lambertian([0.6, 0.1, 0.1]), lambertian([0.1, 0.6, 0.1]), lambertian([0.7, 0.7, 0.7])
+
+
+def _world():
+    two_tone = hittable_list([xy_rect(20, 24, 0, 4, 4, RED), xy_rect(20, 24, 0, 4, 0, RED),
+                              xz_rect(20, 24, 0, 4, 4, RED), xz_rect(20, 24, 0, 4, 0, RED),
+                              yz_rect(0, 4, 0, 4, 24, RED), yz_rect(0, 4, 0, 4, 20, GREEN)])
+    return [box([0, 0, 0], [4, 4, 4], WHITE),                       # shares the identity group with loose rects
+            box([6, 1, -2], [9, 3, 5], RED),                        # a second box in the same group
+            xz_rect(-10, 30, -10, 30, -1, GREEN),                   # floor below everything
+            xy_rect(0, 4, 0, 4, 4, GREEN),                          # coincides with the first box's z = 4 face
+            two_tone,                                               # six rects, two materials
+            translate(rotate_y(box([0, 0, 0], [3, 5, 3], WHITE), 25), [12, 0, 3]),
+            rotate_y(translate(box([0, 0, 0], [2, 2, 2], RED), [1, 6, 1]), -40)]
+
+
+def _rays(rng, n):
+    o = rng.uniform(-6, 28, (n, 3))
+    d = rng.normal(size=(n, 3))
+    k = n // 4
+    o[:k] = rng.uniform(0.2, 3.8, (k, 3))                           # inside the first box
+    o[k:2 * k] = np.array([7.5, 2.0, 1.0]) + rng.uniform(-1, 1, (k, 3))  # inside the second
+    axis = rng.integers(0, 3, n // 8)                               # exactly along an axis
+    d[2 * k:2 * k + n // 8] = 0
+    d[np.arange(2 * k, 2 * k + n // 8), axis] = rng.choice([-1.0, 1.0], n // 8)
+    return o.astype(np.float32), d.astype(np.float32)
+
+
+def test_boxes_against_the_rect_by_rect_oracle(gpu_ctx, oracle):
+    flat = flatten.flatten_world(_world())
+    sc = gpu_ctx.scene(flat)
+    o, d = _rays(np.random.default_rng(41), 40000)
+    dev = sc.hit_batch(o, d)
+    orc = oracle.hit_batch(flat, o, d)
+    assert int(orc[:, 11].sum()) > 20000
+    _check_hits(dev, orc, o, d, 1e-4)
+    sc.close()
+
+
+def test_edges_corners_and_faces_exactly(gpu_ctx, oracle):
+    """Lattice targets approached along directions whose components are powers of two: the
+    device's reciprocals, products and sums are then exact in FP32 as they are in FP64, so ties
+    between faces are real ties on both sides and must fall the same way (the later face in scan
+    order, and the later box)."""
+    flat = flatten.flatten_world([box([0, 0, 0], [4, 4, 4], WHITE), box([4, 0, 0], [8, 4, 4], RED)])
+    sc = gpu_ctx.scene(flat)
+    targets = [(x, y, z) for x in (0, 2, 4, 6, 8) for y in (0, 2, 4) for z in (0, 2, 4)]
+    dirs = [(sx * a, sy * b, sz * c) for (a, b, c) in ((4, 4, 4), (8, 4, 2), (2, 8, 4), (4, 2, 8), (16, 1, 1))
+            for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
+    o, d = [], []
+    for tg in targets:
+        for dv in dirs:
+            for back in (1.0, 0.25):      # from outside, and from near or inside the boxes
+                o.append(np.subtract(tg, np.multiply(dv, back)))
+                d.append(dv)
+    o, d = np.float32(o), np.float32(d)
+    dev = sc.hit_batch(o, d)
+    orc = oracle.hit_batch(flat, o, d)
+    assert _check_hits(dev, orc, o, d, 0.0) <= 1
+    same = (dev["hit"] == orc[:, 11].astype(int))
+    both = same & (dev["hit"] == 1)
+    assert same.all()
+    assert np.array_equal(dev["t"][both], orc[both, 0].astype(np.float32))
+    assert np.array_equal(dev["normal"][both], orc[both, 4:7].astype(np.float32))
+    assert np.array_equal(dev["mat_id"][both], orc[both, 10].astype(np.int32))
+    sc.close()
+
+
+def test_box_as_medium_boundary(gpu_ctx, oracle):
+    """constant_medium.clj:11-20 asks its boundary for the entry over (-inf, inf) and for the exit
+    after it: both come out of the same slab test."""
+    smoke = constant_medium(translate(rotate_y(box([0, 0, 0], [4, 6, 4], WHITE), 15), [1, 0, 2]), 0.3, [0.2, 0.2, 0.2])
+    flat = flatten.flatten_world([smoke, xz_rect(-20, 20, -20, 20, -1, GREEN)])
+    sc = gpu_ctx.scene(flat)
+    rng = np.random.default_rng(8)
+    n = 20000
+    o = rng.uniform(-8, 12, (n, 3)).astype(np.float32)
+    o[: n // 3] = (np.array([3.0, 3.0, 4.0]) + rng.uniform(-1.5, 1.5, (n // 3, 3))).astype(np.float32)  # inside
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    xi = rng.random((n, 1)).astype(np.float32)
+    dev = sc.hit_batch(o, d, medium_xi=xi)
+    orc = oracle.hit_batch(flat, o, d, medium_xi=xi)
+    assert int(orc[:, 11].sum()) > n // 4
+    _check_hits(dev, orc, o, d, 1e-4)
+    sc.close()
