@@ -746,7 +746,12 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
     DPrimInfo I;
     std::memset(&I, 0, sizeof I);
     I.type_group = P.type; I.mat = P.mat; I.chain = G.chain; I.gflags = G.flags;
-    if ((P.type & 15) >= RT_PRIM_XY_RECT) { I.a0 = P.f[0]; I.a1 = P.f[1]; I.b0 = P.f[2]; I.b1 = P.f[3]; I.k = P.f[4]; }
+    if ((P.type & 15) >= RT_PRIM_XY_RECT) {
+      I.a0 = P.f[0]; I.a1 = P.f[1]; I.b0 = P.f[2]; I.b1 = P.f[3]; I.k = P.f[4];
+      I.ox = (P.type & 15) == RT_PRIM_YZ_RECT ? 1.f : 0.f;
+      I.oy = (P.type & 15) == RT_PRIM_XZ_RECT ? 1.f : 0.f;
+      I.oz = (P.type & 15) == RT_PRIM_XY_RECT ? 1.f : 0.f;
+    }
     I.rc = G.rc; I.rs = G.rs; I.bx = G.bx; I.by = G.by; I.bz = G.bz;
     I.mtype = M.type; I.mflags = M.flags; I.mtex = M.tex; I.r = M.r; I.g = M.g; I.b = M.b; I.x = M.x;
     infos[i] = I;

@@ -648,6 +648,7 @@ RT_DEV DPrimInfo fetch_info(PTR p) {
   I.k = p->k; I.rc = p->rc; I.rs = p->rs; I.bx = p->bx; I.by = p->by; I.bz = p->bz;
   I.mtype = p->mtype; I.mflags = p->mflags; I.mtex = p->mtex;
   I.r = p->r; I.g = p->g; I.b = p->b; I.x = p->x;
+  I.ox = p->ox; I.oy = p->oy; I.oz = p->oz;
   return I;
 }
 // Everything about primitive `prim` that its record and scatter need: one round trip, to LDS
@@ -683,12 +684,15 @@ RT_DEV void prim_record(const DScene& S, int prim, const DPrimInfo& I, const Ray
     tally.template add<RT_EV_RECT_RECORD>();
     const float k = I.k;
     V3 p = mk(fmaf(t, r.d.x, r.o.x), fmaf(t, r.d.y, r.o.y), fmaf(t, r.d.z, r.o.z));
-    float a, b, dn;
-    V3 out;
-    if (type == RT_PRIM_XY_RECT) { p.z = k; a = p.x; b = p.y; dn = r.d.z; out = mk(0, 0, 1); }
-    else if (type == RT_PRIM_XZ_RECT) { p.y = k; a = p.x; b = p.z; dn = r.d.y; out = mk(0, 1, 0); }
-    else { p.x = k; a = p.y; b = p.z; dn = r.d.x; out = mk(1, 0, 0); }
+    // Without a per-lane switch on the orientation: `out` is the unit vector of the constant axis,
+    // so both dot products below pick one component exactly, k - p.c is exact for a hit point (it
+    // lies within rounding of the plane) and p.c + (k - p.c) is k.
+    const V3 out = mk(I.ox, I.oy, I.oz);
+    const float dn = fmaf(r.d.x, out.x, fmaf(r.d.y, out.y, r.d.z * out.z));
+    const float off = k - fmaf(p.x, out.x, fmaf(p.y, out.y, p.z * out.z));
+    p = mk(fmaf(out.x, off, p.x), fmaf(out.y, off, p.y), fmaf(out.z, off, p.z));
     if (want_uv) {
+      const float a = (type == RT_PRIM_YZ_RECT) ? p.y : p.x, b = (type == RT_PRIM_XY_RECT) ? p.y : p.z;
       rec.u = (a - I.a0) / (I.a1 - I.a0);
       rec.v = (b - I.b0) / (I.b1 - I.b0);
     }

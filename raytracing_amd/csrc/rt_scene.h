@@ -126,7 +126,7 @@ struct DPrimInfo {
   int32_t mtex;
   float r, g, b;                           // DMat.r g b
   float x;                                 // DMat.x
-  int32_t pad[3];
+  float ox, oy, oz;                        // rects: the unit vector of the constant axis (outward normal)
 };
 #define RT_LDS_PRIMS 256  // scenes up to this many flattened primitives keep DPrimInfo in LDS
 
