@@ -642,12 +642,8 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
     media[m] = dm;
   }
 
-  std::vector<DChain> chains;
-  std::vector<DChainOp> ops;
   std::vector<DChainRec> chain_recs;
   for (auto& c : F.chains) {
-    chains.push_back(DChain{(int)ops.size(), (int)c.size()});
-    ops.insert(ops.end(), c.begin(), c.end());
     // the record side, composed in FP64 from the innermost wrapper outwards (see DChainRec)
     DChainRec rec;
     std::memset(&rec, 0, sizeof rec);
@@ -812,7 +808,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   S.bvh_stack = n_bvh_nodes ? max_height + 1 : 0;
   if (n_bvh_nodes) features |= F_BVH;
   if (d->n_media) features |= F_MEDIA;
-  if (chains.size() > 1) features |= F_CHAINS;
+  if (chain_recs.size() > 1) features |= F_CHAINS;
   S.features = features;
 
   brute_rects.resize(brute_rects.size() + RT_PAIR_STRIDE * RT_PAIR_BATCH, 0.f);  // slack for batched reads
@@ -823,9 +819,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   S.n_prims = (int)prims.size();
   if ((rc = upload(sc, groups, &S.groups))) return rc;
   if ((rc = upload(sc, groups64, &S.groups64))) return rc;
-  if ((rc = upload(sc, chains, &S.chains))) return rc;
   if ((rc = upload(sc, chain_recs, &S.chain_recs))) return rc;
-  if ((rc = upload(sc, ops, &S.ops))) return rc;
   if ((rc = upload(sc, media, &S.media))) return rc;
   if ((rc = upload(sc, mats, &S.mats))) return rc;
   if ((rc = upload(sc, texs, &S.texs))) return rc;
@@ -835,7 +829,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   if ((rc = upload(sc, texels, &S.texels))) return rc;
   S.n_surface_groups = n_surface_groups;
   S.n_groups = (int)groups.size();
-  S.n_chains = (int)chains.size();
+  S.n_chains = (int)chain_recs.size();
   S.n_media = d->n_media;
   S.n_perlin = d->n_perlin;
 
@@ -848,7 +842,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
 
   sc->info.n_prims_flat = (int)prims.size();
   sc->info.n_groups = (int)groups.size();
-  sc->info.n_chains = (int)chains.size();
+  sc->info.n_chains = (int)chain_recs.size();
   sc->info.n_media = d->n_media;
   sc->info.n_bvh_nodes = n_bvh_nodes;
   sc->info.lds_bytes = (int)lds;

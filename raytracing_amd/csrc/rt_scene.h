@@ -53,14 +53,10 @@ struct DPrim {
   };
 };
 
-struct DChainOp {
+struct DChainOp {  // one wrapper of a chain, as the flattener keeps it on the host
   int32_t kind;
   float a, b, c;     // TRANSLATE: offset xyz | ROTATE_Y: sin, cos
   double da, db, dc; // the same in FP64, for groups whose spheres are intersected in FP64
-};
-
-struct DChain {
-  int32_t first_op, n_ops;
 };
 
 // 64 bytes: the record side of a whole chain. On the way back up, every wrapper maps the hit
@@ -184,9 +180,7 @@ struct DScene {
   const DPrimInfo* prim_info;
   const DGroup* groups;
   const DGroup64* groups64;
-  const DChain* chains;
   const DChainRec* chain_recs;
-  const DChainOp* ops;
   const DMedium* media;
   const DBvhNode* nodes;
   const DMat* mats;
