@@ -559,10 +559,34 @@ RT_DEV void brute_rects(const float RT_CONST* R, int n_xy, int n_xz, int n_yz, c
 // instead of points, which differs only where a ray grazes an edge within rounding. Where two
 // faces tie (an edge), the later one in scan order (XY, XZ, YZ faces) wins, as `<=` makes it in
 // the scan.
+struct BoxSlab {
+  f2 tx, ty, tz;   // plane parameters of the faces x0 x1, y0 y1, z0 z1
+  float tn, tf;    // entry = max(near), exit = min(far)
+};
+// w = x0 x1 y0 y1 z0 z1 (wave-uniform)
+RT_DEV BoxSlab box_slab(const float* w, const RayX& r) {
+  BoxSlab s;
+  s.tx = ((f2){w[0], w[1]} - (f2){r.o.x, r.o.x}) * (f2){r.inv.x, r.inv.x};
+  s.ty = ((f2){w[2], w[3]} - (f2){r.o.y, r.o.y}) * (f2){r.inv.y, r.inv.y};
+  s.tz = ((f2){w[4], w[5]} - (f2){r.o.z, r.o.z}) * (f2){r.inv.z, r.inv.z};
+  // fminf/fmaxf drop a NaN operand (0 * inf when the origin lies on a face's plane)
+  const float nx = fminf(s.tx.x, s.tx.y), fx = fmaxf(s.tx.x, s.tx.y);
+  const float ny = fminf(s.ty.x, s.ty.y), fy = fmaxf(s.ty.x, s.ty.y);
+  const float nz = fminf(s.tz.x, s.tz.y), fz = fmaxf(s.tz.x, s.tz.y);
+  s.tn = fmaxf(fmaxf(nx, ny), nz);
+  s.tf = fminf(fminf(fx, fy), fz);
+  return s;
+}
+// The box's answer to `hit` with range [tmin, tmax]: the entry point if it is >= tmin, else the
+// exit point; accepted iff tn <= tf, t >= tmin and t <= tmax — the OR of the three differences'
+// sign bits, as in rect_pair (x - x is +0, so every equality accepts).
+RT_DEV bool box_accept(const BoxSlab& s, float tmin, float tmax, float& t) {
+  t = s.tn >= tmin ? s.tn : s.tf;
+  const int sgn = __float_as_int(s.tf - s.tn) | __float_as_int(t - tmin) | __float_as_int(tmax - t);
+  return sgn >= 0;
+}
 template <class T>
 RT_DEV void brute_boxes(const float RT_CONST* B, int n_box, const RayX& r, float tmin, Best& best, T& tally) {
-  const f2 ox = {r.o.x, r.o.x}, oy = {r.o.y, r.o.y}, oz = {r.o.z, r.o.z};
-  const f2 ix = {r.inv.x, r.inv.x}, iy = {r.inv.y, r.inv.y}, iz = {r.inv.z, r.inv.z};
   for (int b = 0; b < n_box; ++b) {
     float w[RT_BOX_STRIDE];
 #pragma unroll
@@ -571,27 +595,17 @@ RT_DEV void brute_boxes(const float RT_CONST* B, int n_box, const RayX& r, float
     asm volatile("" ::"s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]), "s"(w[4]), "s"(w[5]), "s"(w[6]), "s"(w[7]), "s"(w[8]),
                  "s"(w[9]), "s"(w[10]), "s"(w[11]));
     tally.template add<RT_EV_RECT_TEST>(6);
-    const f2 tx = ((f2){w[0], w[1]} - ox) * ix;
-    const f2 ty = ((f2){w[2], w[3]} - oy) * iy;
-    const f2 tz = ((f2){w[4], w[5]} - oz) * iz;
-    // fminf/fmaxf drop a NaN operand (0 * inf when the origin lies on a face's plane)
-    const float nx = fminf(tx.x, tx.y), fx = fmaxf(tx.x, tx.y);
-    const float ny = fminf(ty.x, ty.y), fy = fmaxf(ty.x, ty.y);
-    const float nz = fminf(tz.x, tz.y), fz = fmaxf(tz.x, tz.y);
-    const float tn = fmaxf(fmaxf(nx, ny), nz), tf = fminf(fminf(fx, fy), fz);
-    const float t = tn >= tmin ? tn : tf;
-    // accepted iff tn <= tf, t >= t-min and t <= closest-so-far: the OR of the three differences'
-    // sign bits, as in rect_pair (x - x is +0, so every equality accepts)
-    const int sgn = __float_as_int(tf - tn) | __float_as_int(t - tmin) | __float_as_int(best.t - t);
-    const bool ok = sgn >= 0;
+    const BoxSlab s = box_slab(w, r);
+    float t;
+    const bool ok = box_accept(s, tmin, best.t, t);
     // the face whose plane gave t; where two planes tie (an edge) the later one in scan order
     // (z0 z1 y0 y1 x0 x1) wins, as the scan's `<=` makes it
     int face = __float_as_int(w[6]);
-    face = tz.y == t ? __float_as_int(w[7]) : face;
-    face = ty.x == t ? __float_as_int(w[8]) : face;
-    face = ty.y == t ? __float_as_int(w[9]) : face;
-    face = tx.x == t ? __float_as_int(w[10]) : face;
-    face = tx.y == t ? __float_as_int(w[11]) : face;
+    face = s.tz.y == t ? __float_as_int(w[7]) : face;
+    face = s.ty.x == t ? __float_as_int(w[8]) : face;
+    face = s.ty.y == t ? __float_as_int(w[9]) : face;
+    face = s.tx.x == t ? __float_as_int(w[10]) : face;
+    face = s.tx.y == t ? __float_as_int(w[11]) : face;
     best.t = ok ? t : best.t;
     best.prim = ok ? face : best.prim;
   }
@@ -759,12 +773,12 @@ RT_DEV void chain_unwind(const X& ctx, int chain, V3 world_d, Rec& rec, T& tally
 
 // -------------------------------------------------------------------------------- media
 // constant_medium.clj:11-38 for medium m; xi is the uniform of line 32 (scripted when have_xi,
-// else drawn from the keyed stream). True with the hit parameter when the free-flight distance
+// else word m & 3 of `block`, the keyed stream's block m >> 2 for this bounce). True with the hit parameter when the free-flight distance
 // ends inside the boundary, t in [t1, t2] within (tmin, tmax]. The boundary groups carry their
 // full chains, so they take the world ray; ray length and t do not depend on the chain.
 template <class X, class T>
 RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax, float xi, bool have_xi,
-                     const Rng& g, uint32_t bounce, float& t_out, T& tally) {
+                     const uint32_t* block, float& t_out, T& tally) {
   const DScene& S = ctx.S;
   const DMedium RT_CONST& M = cptr(S.media)[m];
   const float INF = __builtin_inff();
@@ -794,7 +808,26 @@ RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax,
       b1.prim = b2.prim = G.first_prim;
     }
   }
-  if (!single_sphere) {
+  // A boundary that is one box: both queries read the same slab test (the second one's entry
+  // point can only be the first one's, which its t-min excludes, so it answers with the exit).
+  bool single_box = false;
+  {
+    const DGroup RT_CONST& G = cptr(S.groups)[first_group];
+    single_box = n_groups == 1 && G.bvh_root < 0 && G.n_sph == 0 && G.loose == (1 << 24);
+    if (single_box) {
+      const RayX r = group_ray<X>(S, first_group, G.flags, G.rc, G.rs, G.bx, G.by, G.bz, wr, tally);
+      const float RT_CONST* B = cptr(S.brute_boxes) + G.first_box * RT_BOX_STRIDE;
+      float w[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) w[q] = B[q];
+      tally.template add<RT_EV_RECT_TEST>(12);
+      const BoxSlab s = box_slab(w, r);
+      if (!box_accept(s, -INF, INF, b1.t)) return false;
+      if (!box_accept(s, b1.t + 0.0001f, INF, b2.t)) return false;
+      b1.prim = b2.prim = G.first_prim;
+    }
+  }
+  if (!single_sphere && !single_box) {
     for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, -INF, b1, tally);
     if (b1.prim < 0) return false;
     for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, b1.t + 0.0001f, b2, tally);
@@ -805,9 +838,7 @@ RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax,
   if (!(t1 < t2)) return false;
   if (t1 < 0.0f) t1 = 0.0f;
   if (!have_xi) {
-    uint32_t o4[4];
-    philox(g, (uint32_t)m >> 2, bounce, P_MEDIUM, o4);
-    uint32_t w = (m & 3) == 0 ? o4[0] : (m & 3) == 1 ? o4[1] : (m & 3) == 2 ? o4[2] : o4[3];
+    const uint32_t w = (m & 3) == 0 ? block[0] : (m & 3) == 1 ? block[1] : (m & 3) == 2 ? block[2] : block[3];
     xi = u24(w);
   }
   tally.template add<RT_EV_MEDIUM_SAMPLE>();
@@ -837,9 +868,13 @@ RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, con
   if constexpr (X::has(F_MEDIA)) {
     if (!skip_media) {
       const int n_media = S.n_media;
+      // one block of the keyed stream serves four media: drawn here for every lane, once, instead
+      // of inside each medium for the lanes that cross it
+      uint32_t block[4] = {0u, 0u, 0u, 0u};
       for (int m = 0; m < n_media; ++m) {
+        if (medium_xi == nullptr && (m & 3) == 0) philox(g, (uint32_t)m >> 2, bounce, P_MEDIUM, block);
         float tm;
-        if (medium_t(ctx, m, wr, tmin, best.t, medium_xi ? medium_xi[m] : 0.f, medium_xi != nullptr, g, bounce,
+        if (medium_t(ctx, m, wr, tmin, best.t, medium_xi ? medium_xi[m] : 0.f, medium_xi != nullptr, block,
                      tm, tally)) {
           best.t = tm; best.prim = -2 - m;
         }

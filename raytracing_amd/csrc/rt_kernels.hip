@@ -18,6 +18,9 @@
 #ifndef RT_REGEN_MIN
 #define RT_REGEN_MIN 8
 #endif
+#ifndef RT_WAVES_SMOKE
+#define RT_WAVES_SMOKE 5
+#endif
 #ifndef RT_WAVES_LEAN
 #define RT_WAVES_LEAN 7
 #endif
@@ -136,8 +139,8 @@ constexpr int waves_per_simd(uint32_t feat, bool count) {
   // walks gain more from a third and fourth wave than the texture worlds lose
   if (feat & F_NOISE) return count ? 2 : ((feat & F_DEEP) ? 4 : 3);
   if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : 5;
-  // the smoke worlds' kernel spills at 72 registers once the wave-wide sphere draw is in: six waves measured 4 % faster
-  if (feat & F_MEDIA) return count ? 4 : 6;
+  // the smoke worlds' kernel spills at 72 and at 80 registers: five waves measured 5 % faster than seven
+  if (feat & F_MEDIA) return count ? 4 : RT_WAVES_SMOKE;
   return count ? 4 : RT_WAVES_LEAN;
 }
 
