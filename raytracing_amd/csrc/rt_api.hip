@@ -299,7 +299,7 @@ void fill_camera(const rt_camera* c, const rt_params* p, DCamera& o) {
 
 int fill_render(const rt_scene* sc, const rt_camera* cam, const rt_params* p, DRender& R) {
   if (!cam || !p) return fail(RT_ERR_ARG, "camera or params is NULL");
-  if (p->width <= 0 || p->height <= 0 || (long long)p->width * p->height > (1ll << 28))
+  if (p->width <= 0 || p->height <= 0 || p->width > 65535 || p->height > 65535 || (long long)p->width * p->height > (1ll << 28))
     return fail(RT_ERR_ARG, "image size %dx%d out of range", p->width, p->height);
   if (p->spp <= 0 || p->sample_offset < 0 || p->max_depth < 0 || p->max_depth > (1 << 26))
     return fail(RT_ERR_ARG, "spp %d / sample_offset %d / max_depth %d out of range", p->spp, p->sample_offset, p->max_depth);
@@ -907,7 +907,7 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, cons
 int rt_render(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, float* rgb_sum,
               uint32_t* argb, rt_stats* stats) {
   if (!ctx || !p) return fail(RT_ERR_ARG, "ctx or params is NULL");
-  if (p->width <= 0 || p->height <= 0 || (long long)p->width * p->height > (1ll << 28))
+  if (p->width <= 0 || p->height <= 0 || p->width > 65535 || p->height > 65535 || (long long)p->width * p->height > (1ll << 28))
     return fail(RT_ERR_ARG, "image size %dx%d out of range", p->width, p->height);
   HIPCHK(hipSetDevice(ctx->device));
   size_t npix = (size_t)p->width * p->height;

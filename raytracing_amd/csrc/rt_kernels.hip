@@ -184,7 +184,8 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
   bool have_item = false, active = false, done = false;
   // (the pixel index lives in g.k0 and the current sample index in g.k1: the keys of the path's
   // random stream are the item's bookkeeping)
-  int px = 0, py = 0, chunk_id = 0;
+  uint32_t pxy = 0;  // pixel x | y << 16 (both below 65536)
+  int chunk_id = 0;
   uint32_t k1_end = 0;  // g.k1 of the sample after the item's last
   V3 acc = mk(0.f, 0.f, 0.f);
   Ray ray{mk(0, 0, 0), mk(0, 0, 1), 0.f};
@@ -259,9 +260,10 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
         uint32_t rank = lane_rank(mask);
         if (rank < avail) {
           const int in_tile = (int)((q_next & 63u) + rank);
-          px = q_tx0 + (in_tile & 7);
-          py = q_ty0 + (in_tile >> 3);
+          const int px = q_tx0 + (in_tile & 7);
+          const int py = q_ty0 + (in_tile >> 3);
           if (px < R.width && py < R.height) {
+            pxy = (uint32_t)px | ((uint32_t)py << 16);
             g.k0 = (uint32_t)(py * R.width + px);
             chunk_id = q_chunk;
             g.k1 = (uint32_t)(R.sample_offset + q_s0) - 1u;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       } else {
         {
           const RenderArgs RT_CONST* C = cold();
-          ray = camera_ray(&C->cam, px, py, g, tally);
+          ray = camera_ray(&C->cam, (int)(pxy & 0xFFFFu), (int)(pxy >> 16), g, tally);
         }
         beta = mk(1.f, 1.f, 1.f);
         bounce = 0;

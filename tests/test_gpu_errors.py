@@ -19,7 +19,7 @@ def test_bad_render_arguments(gpu_ctx):
     cfg, flat, cam = scene_bundle("cornell-box")
     sc = gpu_ctx.scene(flat)
     for kw in (dict(width=0), dict(spp=0), dict(shard_index=2, shard_count=2), dict(max_depth=-1),
-               dict(sample_offset=-1)):
+               dict(sample_offset=-1), dict(width=70000)):
         args = dict(width=8, height=8, spp=1)
         args.update(kw)
         with pytest.raises(lib.RtError) as ei:
