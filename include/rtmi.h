@@ -144,7 +144,7 @@ typedef struct rt_camera {
  * over devices or calls reproduces the same per-sample radiance.
  */
 typedef struct rt_params {
-  int32_t width, height;
+  int32_t width, height;  /* each 1..65535, width*height <= 2^28                       */
   int32_t spp;            /* samples rendered by THIS call per pixel                      */
   int32_t sample_offset;  /* global index of this call's first sample (sample slicing)   */
   int32_t max_depth;      /* core.clj:58 (50)                                             */
