@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Cornell box 1024x1024 @ 1000 spp (BASELINE.json configs[3]), Msamples/s.
+"""Headline benchmark: Cornell box 1024x1024 @ 1000 spp (the configuration the headline metric is quoted on), Msamples/s.
 
 A step = one complete render of that workload: every rank renders its tile shard (rank r owns
 the 8x8 tiles t with t % N == r), the per-GPU FP32 accumulators are summed onto rank 0 with one

@@ -326,7 +326,7 @@ def test_event_counters_are_consistent(gpu_ctx):
 
 
 def test_full_size_cornell_properties(gpu_ctx):
-    """BASELINE's headline configuration (1024x1024 Cornell) at a few samples per pixel, checked
+    """The headline configuration (1024x1024 Cornell) at a few samples per pixel, checked
     through size-independent properties instead of the oracle (which would take minutes)."""
     cfg, flat, cam = scene_bundle("cornell-box")
     sc = gpu_ctx.scene(flat)
@@ -351,11 +351,11 @@ def test_full_size_cornell_properties(gpu_ctx):
 
 
 @pytest.mark.parametrize("name,W,H,spp,rays_lo,rays_hi", [
-    ("random-scene", 1200, 800, 4, 2.0, 3.5),    # BASELINE configs[1]: 489 spheres under a GPU-built BVH
-    ("final-scene", 3840, 2160, 2, 1.7, 3.2),    # BASELINE configs[4]: the 4K frame, BVHs + media + textures
+    ("random-scene", 1200, 800, 4, 2.0, 3.5),    # the random-spheres size: 489 spheres under a BVH
+    ("final-scene", 3840, 2160, 2, 1.7, 3.2),    # the 4K frame: BVHs + media + textures
 ])
 def test_full_size_bvh_worlds_properties(gpu_ctx, name, W, H, spp, rays_lo, rays_hi):
-    """The other BASELINE sizes at a few samples per pixel, through size-independent properties:
+    """The other full benchmark sizes at a few samples per pixel, through size-independent properties:
     every sample accounted for, finite non-negative radiance, sample slices that add up to the
     whole, and block means that agree with a low-resolution render of the same world."""
     cfg, flat, cam = scene_bundle(name)

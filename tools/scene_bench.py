@@ -1,5 +1,5 @@
-"""Throughput of the path kernel on every reference world at the sizes BASELINE.json's configs
-name (reduced spp): Msamples/s, rays/sample, kernel ms. Usage: python tools/scene_bench.py [scene ...]"""
+"""Throughput of the path kernel on every reference world at its full benchmark size
+(reduced spp): Msamples/s, rays/sample, kernel ms. Usage: python tools/scene_bench.py [scene ...]"""
 import sys
 from raytracing_amd import abi, lib
 from raytracing_amd.core import build_camera, setup
