@@ -804,7 +804,14 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
     node_base += n_prims - 1;
     max_height = std::max(max_height, height);
   }
-  S.nodes = d_nodes;
+  {  // the traversal reads the packed form
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, sizeof(DBvhNode16) * (size_t)std::max(n_bvh_nodes, 1)));
+    sc->allocs.push_back(p);
+    hipError_t e = pack_bvh_nodes(d_nodes, static_cast<DBvhNode16*>(p), n_bvh_nodes, 0);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "BVH packing failed: %s", hipGetErrorString(e));
+    S.nodes = static_cast<const DBvhNode16*>(p);
+  }
   S.bvh_stack = n_bvh_nodes ? max_height + 1 : 0;
   if (n_bvh_nodes) features |= F_BVH;
   if (d->n_media) features |= F_MEDIA;

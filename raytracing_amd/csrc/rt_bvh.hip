@@ -8,6 +8,7 @@
 // and a bottom-up box fit done as one kernel launch per tree level (kernel boundaries give the
 // cross-workgroup visibility a single-launch atomic scheme would have to fence for).
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 
 #include <algorithm>
 #include <cmath>
@@ -206,6 +207,33 @@ __global__ void k_fit_pass(const Box* __restrict__ boxes, int n, int first, int 
   height[i] = 1 + max(ch[0], ch[1]);
   ready[i] = pass;
 }
+
+__global__ void k_pack_nodes(const DBvhNode* __restrict__ nodes, DBvhNode16* __restrict__ packed, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const DBvhNode N = nodes[i];
+  DBvhNode16 P;
+  for (int a = 0; a < 3; ++a) {
+    P.lmin[a] = __half_as_ushort(__float2half_rd(N.lmin[a]));
+    P.lmax[a] = __half_as_ushort(__float2half_ru(N.lmax[a]));
+    P.rmin[a] = __half_as_ushort(__float2half_rd(N.rmin[a]));
+    P.rmax[a] = __half_as_ushort(__float2half_ru(N.rmax[a]));
+  }
+  P.left = N.left; P.right = N.right;
+  packed[i] = P;
+}
+
+}  // namespace
+
+hipError_t pack_bvh_nodes(const DBvhNode* d_nodes, DBvhNode16* d_packed, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_nodes, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, d_packed, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(stream);
+}
+
+namespace {
 
 }  // namespace
 

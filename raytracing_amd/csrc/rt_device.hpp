@@ -417,13 +417,18 @@ RT_DEV RayX group_ray(const DScene& S, int g, int gflags, float rc, float rs, fl
 }
 
 // ---------------------------------------------------------------------------------- BVH
-RT_DEV bool slab(const float* mn, const float* mx, const RayX& r, float tmin, float tmax, float& tnear) {
-  float t0x = (mn[0] - r.o.x) * r.inv.x, t1x = (mx[0] - r.o.x) * r.inv.x;
-  float t0y = (mn[1] - r.o.y) * r.inv.y, t1y = (mx[1] - r.o.y) * r.inv.y;
-  float t0z = (mn[2] - r.o.z) * r.inv.z, t1z = (mx[2] - r.o.z) * r.inv.z;
-  // fminf/fmaxf drop a NaN operand (0 * inf when the origin lies on a slab plane)
-  float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-  float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+// One child box of a packed node against the ray: lo_hi = (min | max << 16 ... as stored), the
+// six bounds arrive as FP16 halves and go into the FMAs as they are (v_fma_mix_f32).
+// t = bound * (1/d) - o/d: less exact than (bound - o) * (1/d) when the origin is far from the box
+// relative to its size, by a few ulps of o/d; the boxes' outward rounding covers that many times.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+RT_DEV bool slab16(_Float16 mnx, _Float16 mny, _Float16 mnz, _Float16 mxx, _Float16 mxy, _Float16 mxz, V3 inv, V3 oi,
+                   float tmin, float tmax, float& tnear) {
+  const float t0x = fmaf((float)mnx, inv.x, -oi.x), t1x = fmaf((float)mxx, inv.x, -oi.x);
+  const float t0y = fmaf((float)mny, inv.y, -oi.y), t1y = fmaf((float)mxy, inv.y, -oi.y);
+  const float t0z = fmaf((float)mnz, inv.z, -oi.z), t1z = fmaf((float)mxz, inv.z, -oi.z);
+  const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+  const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
   tnear = tn;
   return tn <= tf;
 }
@@ -439,23 +444,30 @@ RT_DEV bool slab(const float* mn, const float* mx, const RayX& r, float tmin, fl
 template <class X, class T>
 RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best& best, T& tally) {
   const DScene& S = ctx.S;
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const f4 RT_CONST* nodes4 = reinterpret_cast<const f4 RT_CONST*>(cptr(S.nodes));
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  const u4 RT_CONST* nodes4 = reinterpret_cast<const u4 RT_CONST*>(cptr(S.nodes));
+  // 1/d clamped to +-1e30: with an infinite reciprocal (a ray along an axis) bound * inf - o * inf
+  // is inf - inf; with the clamp the two parameters of that axis are huge and of opposite sign when
+  // the origin lies between the bounds, of the same sign when it does not, as they should be.
+  const V3 inv = mk(__builtin_amdgcn_fmed3f(r.inv.x, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(r.inv.y, -1e30f, 1e30f),
+                    __builtin_amdgcn_fmed3f(r.inv.z, -1e30f, 1e30f));
+  const V3 oi = mk(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
   int sp = 0;
   int node = root;
   while (node != RT_BVH_DONE) {
     while ((unsigned)node < (unsigned)RT_BVH_DONE) {  // internal
-      const f4 q0 = nodes4[node * 4 + 0];
-      const f4 q1 = nodes4[node * 4 + 1];
-      const f4 q2 = nodes4[node * 4 + 2];
-      const f4 q3 = nodes4[node * 4 + 3];
-      const float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
-      const float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
-      const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+      const u4 q0 = nodes4[node * 2 + 0];
+      const u4 q1 = nodes4[node * 2 + 1];
+      // halves in storage order: lmin xyz, lmax xyz, rmin xyz, rmax xyz
+      // (plain scalars first: a bit cast applied to a vector element reads the vector's first one)
+      const uint32_t w0 = q0.x, w1 = q0.y, w2 = q0.z, w3 = q0.w, w4 = q1.x, w5 = q1.y;
+      const h2 a0 = __builtin_bit_cast(h2, w0), a1 = __builtin_bit_cast(h2, w1), a2 = __builtin_bit_cast(h2, w2);
+      const h2 a3 = __builtin_bit_cast(h2, w3), a4 = __builtin_bit_cast(h2, w4), a5 = __builtin_bit_cast(h2, w5);
+      const int left = (int)q1.z, right = (int)q1.w;
       float tl, tr;
       tally.template add<RT_EV_AABB_TEST>(2);
-      const bool hl = slab(lmin, lmax, r, tmin, best.t, tl);
-      const bool hr = slab(rmin, rmax, r, tmin, best.t, tr);
+      const bool hl = slab16(a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, inv, oi, tmin, best.t, tl);
+      const bool hr = slab16(a3.x, a3.y, a4.x, a4.y, a5.x, a5.y, inv, oi, tmin, best.t, tr);
       if (hl && hr) {
         const bool swap = tr < tl;
         ctx.lds_stack[sp * ctx.stack_stride] = swap ? left : right;

@@ -35,5 +35,8 @@ hipError_t build_bvh(const DPrim* d_prims, int first, int n, DBvhNode* d_nodes, 
 hipError_t build_bvh_sah(const DPrim* h_prims, int first, int n, DBvhNode* d_nodes, int node_base, float time_lo,
                          float time_hi, int* height, hipStream_t stream);
 
+// Packs n nodes into the 32-byte form the traversal reads (FP16 boxes rounded outwards).
+hipError_t pack_bvh_nodes(const DBvhNode* d_nodes, DBvhNode16* d_packed, int n, hipStream_t stream);
+
 }  // namespace rt
 #endif

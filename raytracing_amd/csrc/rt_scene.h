@@ -142,6 +142,15 @@ struct DBvhNode {
   int32_t left, right;
   int32_t pad[2];
 };
+// What the traversal reads: the same node in 32 bytes, the boxes as FP16 rounded outwards (minima
+// down, maxima up), so a step fetches half as much per lane and the slab test takes its operands
+// straight from the halves (v_fma_mix_f32). A box can only grow: nothing is culled that the FP32
+// node would keep.
+struct DBvhNode16 {
+  uint16_t lmin[3], lmax[3];
+  uint16_t rmin[3], rmax[3];
+  int32_t left, right;
+};
 
 struct DMat {
   int32_t type;   // RT_MAT_*
@@ -182,7 +191,7 @@ struct DScene {
   const DGroup64* groups64;
   const DChainRec* chain_recs;
   const DMedium* media;
-  const DBvhNode* nodes;
+  const DBvhNode16* nodes;
   const DMat* mats;
   const DTex* texs;
   const float* perlin_vec;       // n_perlin * 256 * 4 (xyz + pad)
