@@ -52,7 +52,7 @@ struct rt_ctx {
   int device = 0;
   int n_cu = 0;
   // reusable device workspace
-  uint32_t* d_queue = nullptr;              // 1 word: head of the work-item queue
+  uint32_t* d_queue = nullptr;              // the heads of the work-item queue (RT_QUEUE_HEADS lines)
   unsigned long long* d_stats = nullptr;    // 2 + RT_EV_COUNT words
   float* d_partial = nullptr;               // n_chunks * W*H*3 partial sums
   size_t partial_bytes = 0;
@@ -386,7 +386,7 @@ int rt_init(int32_t device_id, rt_ctx** out) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device_id));
   ctx->n_cu = prop.multiProcessorCount;
-  HIPCHK(hipMalloc(&ctx->d_queue, 256));
+  HIPCHK(hipMalloc(&ctx->d_queue, RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4));
   HIPCHK(hipMalloc(&ctx->d_stats, sizeof(unsigned long long) * (2 + RT_EV_COUNT)));
   HIPCHK(hipEventCreate(&ctx->ev0));
   HIPCHK(hipEventCreate(&ctx->ev1));
@@ -885,7 +885,7 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, cons
     HIPCHK(hipMalloc(&ctx->d_partial, need));
     ctx->partial_bytes = need;
   }
-  HIPCHK(hipMemsetAsync(ctx->d_queue, 0, 256, stream));
+  HIPCHK(hipMemsetAsync(ctx->d_queue, 0, RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4, stream));
   HIPCHK(hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (2 + RT_EV_COUNT), stream));
   // persistent grid: as many workgroups as stay resident, never more than there is work for
   int grid = ctx->n_cu * sc->blocks_per_cu[count ? 1 : 0];

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
 
   // wave-uniform queue window [q_next, q_end) of work items taken from the global queue
   uint32_t q_next = 0, q_end = 0;
+  uint32_t q_head = blockIdx.x % RT_QUEUE_HEADS, q_heads_dry = 0;  // the head this wave takes from; heads found empty
   bool q_dry = false;
   int q_chunk = 0, q_tx0 = 0, q_ty0 = 0, q_s0 = 0, q_s1 = 0;  // what the window's items share
 
@@ -234,10 +235,27 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
         // A window is 64 consecutive items = the 64 pixels of ONE tile for ONE chunk (n_items is a
         // multiple of 64), so the item is decoded once per window on wave-uniform values and a
         // lane only adds its place in the tile.
-        uint32_t base = 0;
-        if (wave_lane() == 0) base = atomicAdd(C->queue, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= (uint32_t)C->R.n_items) {
+        // The queue has RT_QUEUE_HEADS heads, each owning one window of every block of RT_QUEUE_HEADS: atomics
+        // on ONE address go through at about 90 M/s, which held every light world at few samples
+        // per pixel to the same 5.5 G samples/s. A wave starts on the head of its workgroup
+        // (workgroups go round the XCDs, so a head is mostly hit from one L2) and moves on to the
+        // next one when it finds its own empty; after a full round the queue is dry.
+        const uint32_t n_windows = (uint32_t)C->R.n_items >> 6;
+        uint32_t base = ~0u;
+        while (q_heads_dry < RT_QUEUE_HEADS) {  // wave-uniform
+          uint32_t k = 0;
+          if (wave_lane() == 0) k = atomicAdd(C->queue + q_head * RT_QUEUE_STRIDE, 1u);
+          k = __builtin_amdgcn_readfirstlane(k);
+          // (k < 2^26: at most n_windows / RT_QUEUE_HEADS + one miss per wave)
+          // within each block of RT_QUEUE_HEADS windows the heads take turns (rotated by k and by
+          // k / 8): a head that always got the same place in a block would own fixed tile columns
+          // of the image, and columns differ in cost
+          const uint32_t w = k * RT_QUEUE_HEADS + ((q_head + k + (k >> 3)) % RT_QUEUE_HEADS);
+          if (w < n_windows) { base = w << 6; break; }
+          q_head = (q_head + 1u) % RT_QUEUE_HEADS;
+          ++q_heads_dry;
+        }
+        if (base == ~0u) {
           q_dry = true;
         } else {
           q_next = base;

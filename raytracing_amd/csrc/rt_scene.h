@@ -21,6 +21,8 @@
 #define RT_MAX_PERLIN_LDS 8    // Perlin table sets staged in LDS
 #define RT_MAX_CHUNKS 128      // work items per pixel, at most
 #define RT_TILE 8              // pixels per tile edge; one wave64 = one 8x8 tile
+#define RT_QUEUE_HEADS 8        // the work-item queue has this many heads (one window of every 8 each)
+#define RT_QUEUE_STRIDE 32      // dwords between two heads (each on a 128-byte line of its own)
 #define RT_PAIR_STRIDE 12      // dwords per pair record of DScene.brute_rects
 #define RT_BOX_STRIDE 12       // dwords per box record of DScene.brute_boxes
 #define RT_PAIR_BATCH 3        // pair records the brute-force loop fetches per scalar-memory round trip
