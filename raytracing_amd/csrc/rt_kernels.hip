@@ -18,6 +18,21 @@
 #ifndef RT_REGEN_MIN
 #define RT_REGEN_MIN 8
 #endif
+#ifndef RT_WAVES_SPH
+#define RT_WAVES_SPH 5
+#endif
+#ifndef RT_WAVES_ALL
+#define RT_WAVES_ALL 3
+#endif
+#ifndef RT_WAVES_DEEP
+#define RT_WAVES_DEEP 4
+#endif
+#ifndef RT_REGEN_SMOKE
+#define RT_REGEN_SMOKE 1
+#endif
+#ifndef RT_REGEN_REST
+#define RT_REGEN_REST 1
+#endif
 #ifndef RT_WAVES_SMOKE
 #define RT_WAVES_SMOKE 5
 #endif
@@ -137,8 +152,8 @@ __device__ __forceinline__ bool path_step(const XC& X, const DRender& R, Ray& ra
 constexpr int waves_per_simd(uint32_t feat, bool count) {
   // the all-features kernel wants 211 registers; squeezing it costs a few spills but the long BVH
   // walks gain more from a third and fourth wave than the texture worlds lose
-  if (feat & F_NOISE) return count ? 2 : ((feat & F_DEEP) ? 4 : 3);
-  if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : 5;
+  if (feat & F_NOISE) return count ? 2 : ((feat & F_DEEP) ? RT_WAVES_DEEP : RT_WAVES_ALL);
+  if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : RT_WAVES_SPH;
   // the smoke worlds' kernel spills at 72 and at 80 registers: five waves measured 5 % faster than seven
   if (feat & F_MEDIA) return count ? 4 : RT_WAVES_SMOKE;
   return count ? 4 : RT_WAVES_LEAN;
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
     // Lanes whose path ended wait until `regen_min` of them are idle: the refill and camera code
     // below runs for the whole wave however few lanes want it. Worth it where paths are long and the
     // loop is lean (the rect-only kernel: +2 % at 8, flat to worse from 16 on and elsewhere).
-    constexpr int regen_min = ((FEAT & F_SMALL) != 0 && (FEAT & F_MEDIA) == 0) ? RT_REGEN_MIN : 1;
+    constexpr int regen_min = ((FEAT & F_SMALL) != 0 && (FEAT & F_MEDIA) == 0) ? RT_REGEN_MIN : ((FEAT & F_SMALL) != 0 ? RT_REGEN_SMOKE : RT_REGEN_REST);
     // (With no path left in the wave the idle lanes go ahead whatever their number: every lane must
     // reach `done`.)
     const bool regen = __popcll(__ballot(!active && !done)) >= regen_min || __ballot(active) == 0ull;
