@@ -876,7 +876,7 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, cons
   fill_camera(cam, p, C);
   const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
   const size_t npix = (size_t)R.width * R.height;
-  const size_t need = npix * 3 * sizeof(float) * (size_t)R.n_chunks;
+  const size_t need = (size_t)std::max(R.n_items, 1) * 3 * sizeof(float);  // one slot per work item
   if (ctx->partial_bytes < need) {
     HIPCHK(hipStreamSynchronize(stream));
     if (ctx->d_partial) HIPCHK(hipFree(ctx->d_partial));

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
   // (the pixel index lives in g.k0 and the current sample index in g.k1: the keys of the path's
   // random stream are the item's bookkeeping)
   uint32_t pxy = 0;  // pixel x | y << 16 (both below 65536)
-  int chunk_id = 0;
+  uint32_t item = 0;  // the lane's work item = its slot in the partial-sum slab
   uint32_t k1_end = 0;  // g.k1 of the sample after the item's last
   V3 acc = mk(0.f, 0.f, 0.f);
   Ray ray{mk(0, 0, 0), mk(0, 0, 1), 0.f};
@@ -239,7 +239,9 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
     bool need = regen && !active && !done && !(have_item && g.k1 + 1u != k1_end);
     if (need && have_item) {
       // core.clj:115-120 finished for this chunk: store the partial sum of its samples
-      size_t o = ((size_t)chunk_id * npix + g.k0) * 3;
+      // (items are numbered chunk by chunk, tile by tile: the 64 lanes of a window write 768
+      // contiguous bytes)
+      size_t o = (size_t)item * 3;
       out[o] = acc.x; out[o + 1] = acc.y; out[o + 2] = acc.z;
       have_item = false;
     }
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
           if (px < R.width && py < R.height) {
             pxy = (uint32_t)px | ((uint32_t)py << 16);
             g.k0 = (uint32_t)(py * R.width + px);
-            chunk_id = q_chunk;
+            item = q_next + rank;
             g.k1 = (uint32_t)(R.sample_offset + q_s0) - 1u;
             k1_end = (uint32_t)(R.sample_offset + q_s1);
             acc = mk(0.f, 0.f, 0.f);
@@ -409,8 +411,11 @@ __global__ void k_resolve(DRender R, const float* __restrict__ partial, float* _
   int tile = (y / RT_TILE) * R.tiles_x + (x / RT_TILE);
   float r = 0.f, g = 0.f, b = 0.f;
   if (tile % R.shard_count == R.shard_index) {
+    // the slab is indexed by work item: chunk, then owned tile, then place in the tile
+    const size_t items_per_chunk = (size_t)R.n_owned_tiles * 64;
+    const size_t in_chunk = (size_t)(tile / R.shard_count) * 64 + (size_t)((y % RT_TILE) * RT_TILE + x % RT_TILE);
     for (int c = 0; c < R.n_chunks; ++c) {
-      size_t o = ((size_t)c * npix + pix) * 3;
+      size_t o = ((size_t)c * items_per_chunk + in_chunk) * 3;
       r += partial[o]; g += partial[o + 1]; b += partial[o + 2];
     }
   }
