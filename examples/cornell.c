@@ -4,7 +4,10 @@
  * renders it with the constants of -main (core.clj:52-59,89-91) and writes a binary PPM
  * (top row first, i.e. the row flip of core.clj:123-126 without its margins).
  *
- *   cornell [width height spp out.ppm [argb.bin]]      defaults: 256 256 64 cornell.ppm
+ *   cornell [width height spp out.ppm [argb.bin [scene.rtscn]]]   defaults: 256 256 64 cornell.ppm
+ *
+ * With a sixth argument the description is first written there as a scene file (rt_scene_write)
+ * and the world is created from that file (rt_scene_create_from_file) instead of from memory.
  *
  * Build: make -C raytracing_amd/csrc example
  */
@@ -113,6 +116,7 @@ int main(int argc, char** argv) {
   int W = argc > 1 ? atoi(argv[1]) : 256, H = argc > 2 ? atoi(argv[2]) : 256, spp = argc > 3 ? atoi(argv[3]) : 64;
   const char* out = argc > 4 ? argv[4] : "cornell.ppm";
   const char* raw = argc > 5 ? argv[5] : NULL;
+  const char* scene_path = argc > 6 ? argv[6] : NULL;
 
   /* materials: red, white, green Lambertians over solid colours, one diffuse light (scenes.clj:72-75) */
   enum { RED, WHITE, GREEN, LIGHT };
@@ -155,7 +159,19 @@ int main(int argc, char** argv) {
   rt_ctx* ctx = NULL;
   rt_scene* scene = NULL;
   CHECK(rt_init(0, &ctx));
-  CHECK(rt_scene_create(ctx, &d, &scene));
+  if (scene_path) {
+    uint64_t n = rt_scene_file_size(&d), written = 0;
+    if (!n) { fprintf(stderr, "rt_scene_file_size: %s\n", rt_last_error()); return 1; }
+    void* blob = malloc((size_t)n);
+    CHECK(rt_scene_write(&d, blob, n, &written));
+    FILE* sf = fopen(scene_path, "wb");
+    if (!sf || fwrite(blob, 1, (size_t)written, sf) != written) { perror(scene_path); return 1; }
+    fclose(sf);
+    free(blob);
+    CHECK(rt_scene_create_from_file(ctx, scene_path, &scene));
+  } else {
+    CHECK(rt_scene_create(ctx, &d, &scene));
+  }
   uint32_t* argb = (uint32_t*)malloc((size_t)W * H * 4);
   rt_stats st;
   CHECK(rt_render(ctx, scene, &cam, &p, NULL, argb, &st));

@@ -239,6 +239,35 @@ int rt_sample_batch(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam,
                     const rt_params* params, int32_t n, const int32_t* px, const int32_t* smp,
                     float* out_rgb);
 
+/*
+ * Scene files: the rt_scene_desc as one little-endian blob, so that a host that cannot
+ * pass nested pointers comfortably (the JVM) writes bytes and hands over one buffer or path.
+ * The reference has no scene format; this stands in for passing the `world` vector of
+ * core.clj:66-88 by reference.
+ *
+ *   offset 0   char    magic[8] = "RTMISCN1"
+ *          8   int32   abi_version
+ *         12   int32   n_prims, n_nodes, n_children, root, n_media, n_mats, n_tex, n_perlin,
+ *                      n_images
+ *         48   int32   reserved[4] = 0
+ *         64   the arrays of rt_scene_desc in struct order (prim_type, prim_d, prim_mat,
+ *              node_kind, node_i, node_d, node_children, mat_type, mat_d, mat_tex, tex_type,
+ *              tex_d, tex_i, perlin_ranvec, perlin_perm, img_w, img_h), then image 0 ..
+ *              n_images-1 (h*w*3 bytes, top row first, R G B); every array and image is
+ *              zero-padded to a multiple of 8 bytes, so all offsets follow from the counts.
+ *
+ * rt_scene_file_size: bytes rt_scene_write produces for `desc`, 0 if the description is
+ *   invalid (rt_last_error says why). Neither needs a context or a device.
+ * rt_scene_write: fills `bytes` (capacity >= that size); equal descriptions give equal bytes.
+ * rt_scene_create_from_memory / _from_file: validate the blob (magic, counts, truncation)
+ *   and then behave exactly as rt_scene_create on the description it holds; the buffer is
+ *   only read during the call.
+ */
+uint64_t rt_scene_file_size(const rt_scene_desc* desc);
+int rt_scene_write(const rt_scene_desc* desc, void* bytes, uint64_t capacity, uint64_t* written);
+int rt_scene_create_from_memory(rt_ctx* ctx, const void* bytes, uint64_t n_bytes, rt_scene** out);
+int rt_scene_create_from_file(rt_ctx* ctx, const char* path, rt_scene** out);
+
 /* Introspection for tests and reports. */
 typedef struct rt_scene_info {
   int32_t n_prims_flat;   /* leaves reachable from the root, deduplicated          */

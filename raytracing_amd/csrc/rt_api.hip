@@ -875,7 +875,6 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, cons
   DCamera C;
   fill_camera(cam, p, C);
   const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
-  const size_t npix = (size_t)R.width * R.height;
   const size_t need = (size_t)std::max(R.n_items, 1) * 3 * sizeof(float);  // one slot per work item
   if (ctx->partial_bytes < need) {
     HIPCHK(hipStreamSynchronize(stream));
@@ -999,6 +998,180 @@ int rt_sample_batch(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const
   HIPCHK(launch_sample_batch(sc->S, C, R, n, d_px, d_smp, d_out, 0));
   HIPCHK(hipMemcpy(out_rgb, d_out, bo, hipMemcpyDeviceToHost));
   return RT_OK;
+}
+
+// ------------------------------------------------------------------------------- scene files
+// A scene file is the rt_scene_desc as one little-endian blob: a 64-byte header (magic, ABI version,
+// the nine counts in struct order) and then every array of the struct in struct order, each padded
+// to a multiple of 8 bytes, the images last (h*w*3 bytes each). The offsets follow from the counts,
+// so a file can be mapped and pointed into without a parse step.
+namespace {
+
+constexpr char kSceneMagic[8] = {'R', 'T', 'M', 'I', 'S', 'C', 'N', '1'};
+constexpr uint64_t kSceneHeader = 64;
+
+struct SceneSpans {  // byte offset of every array, and the total
+  uint64_t prim_type, prim_d, prim_mat, node_kind, node_i, node_d, node_children, mat_type, mat_d, mat_tex, tex_type,
+      tex_d, tex_i, perlin_ranvec, perlin_perm, img_w, img_h, images, total;
+};
+
+uint64_t pad8(uint64_t x) { return (x + 7u) & ~(uint64_t)7u; }
+
+// offsets up to the image sizes (`images`); `total` is filled once the sizes are known
+SceneSpans scene_spans(const int32_t c[9]) {
+  const uint64_t n_prims = c[0], n_nodes = c[1], n_children = c[2], n_mats = c[5], n_tex = c[6], n_perlin = c[7], n_images = c[8];
+  SceneSpans s{};
+  uint64_t o = kSceneHeader;
+  auto take = [&](uint64_t& field, uint64_t bytes) { field = o; o += pad8(bytes); };
+  take(s.prim_type, n_prims * 4);
+  take(s.prim_d, n_prims * RT_PRIM_STRIDE * 8);
+  take(s.prim_mat, n_prims * 4);
+  take(s.node_kind, n_nodes * 4);
+  take(s.node_i, n_nodes * RT_NODE_ISTRIDE * 4);
+  take(s.node_d, n_nodes * RT_NODE_DSTRIDE * 8);
+  take(s.node_children, n_children * 4);
+  take(s.mat_type, n_mats * 4);
+  take(s.mat_d, n_mats * RT_MAT_DSTRIDE * 8);
+  take(s.mat_tex, n_mats * 4);
+  take(s.tex_type, n_tex * 4);
+  take(s.tex_d, n_tex * RT_TEX_DSTRIDE * 8);
+  take(s.tex_i, n_tex * RT_TEX_ISTRIDE * 4);
+  take(s.perlin_ranvec, n_perlin * 256 * 3 * 8);
+  take(s.perlin_perm, n_perlin * 3 * 256 * 4);
+  take(s.img_w, n_images * 4);
+  take(s.img_h, n_images * 4);
+  s.images = o;
+  s.total = o;
+  return s;
+}
+
+void desc_counts(const rt_scene_desc* d, int32_t c[9]) {
+  c[0] = d->n_prims; c[1] = d->n_nodes; c[2] = d->n_children; c[3] = d->root; c[4] = d->n_media;
+  c[5] = d->n_mats; c[6] = d->n_tex; c[7] = d->n_perlin; c[8] = d->n_images;
+}
+
+// Points `d` into a blob (8-byte aligned, n bytes); `imgs` receives the per-image pointers.
+int desc_from_blob(const unsigned char* b, uint64_t n, rt_scene_desc* d, std::vector<const uint8_t*>& imgs) {
+  if (n < kSceneHeader || memcmp(b, kSceneMagic, 8) != 0) return fail(RT_ERR_ARG, "not a scene file (bad magic or shorter than its header)");
+  int32_t head[14];
+  memcpy(head, b + 8, sizeof head);
+  const int32_t* c = head + 1;
+  for (int i = 0; i < 9; ++i)
+    if (c[i] < 0 || c[i] > (1 << 28)) return fail(RT_ERR_ARG, "scene file: count %d out of range", i);
+  SceneSpans s = scene_spans(c);
+  if (s.images > n) return fail(RT_ERR_ARG, "scene file truncated: arrays need %llu bytes, file has %llu", (unsigned long long)s.images, (unsigned long long)n);
+  memset(d, 0, sizeof *d);
+  d->abi_version = head[0];
+  d->n_prims = c[0]; d->n_nodes = c[1]; d->n_children = c[2]; d->root = c[3]; d->n_media = c[4];
+  d->n_mats = c[5]; d->n_tex = c[6]; d->n_perlin = c[7]; d->n_images = c[8];
+  auto i32 = [&](uint64_t o) { return reinterpret_cast<const int32_t*>(b + o); };
+  auto f64 = [&](uint64_t o) { return reinterpret_cast<const double*>(b + o); };
+  d->prim_type = i32(s.prim_type); d->prim_d = f64(s.prim_d); d->prim_mat = i32(s.prim_mat);
+  d->node_kind = i32(s.node_kind); d->node_i = i32(s.node_i); d->node_d = f64(s.node_d);
+  d->node_children = i32(s.node_children);
+  d->mat_type = i32(s.mat_type); d->mat_d = f64(s.mat_d); d->mat_tex = i32(s.mat_tex);
+  d->tex_type = i32(s.tex_type); d->tex_d = f64(s.tex_d); d->tex_i = i32(s.tex_i);
+  d->perlin_ranvec = f64(s.perlin_ranvec); d->perlin_perm = i32(s.perlin_perm);
+  d->img_w = i32(s.img_w); d->img_h = i32(s.img_h);
+  imgs.assign((size_t)d->n_images, nullptr);
+  uint64_t o = s.images;
+  for (int i = 0; i < d->n_images; ++i) {
+    const int64_t w = d->img_w[i], h = d->img_h[i];
+    if (w <= 0 || h <= 0 || w > 65536 || h > 65536) return fail(RT_ERR_ARG, "scene file: image %d has size %lld x %lld", i, (long long)w, (long long)h);
+    const uint64_t bytes = (uint64_t)w * (uint64_t)h * 3u;
+    if (o + bytes > n) return fail(RT_ERR_ARG, "scene file truncated inside image %d", i);
+    imgs[(size_t)i] = b + o;
+    o += pad8(bytes);
+  }
+  d->img_rgb8 = imgs.data();
+  return RT_OK;
+}
+
+}  // namespace
+
+uint64_t rt_scene_file_size(const rt_scene_desc* d) {
+  if (validate_desc(d) != RT_OK) return 0;
+  int32_t c[9];
+  desc_counts(d, c);
+  uint64_t total = scene_spans(c).images;
+  for (int i = 0; i < d->n_images; ++i) total += pad8((uint64_t)d->img_w[i] * (uint64_t)d->img_h[i] * 3u);
+  return total;
+}
+
+int rt_scene_write(const rt_scene_desc* d, void* bytes, uint64_t capacity, uint64_t* written) {
+  const uint64_t total = rt_scene_file_size(d);
+  if (!total) return RT_ERR_ARG;  // message set by the validation
+  if (!bytes || capacity < total) return fail(RT_ERR_ARG, "scene file needs %llu bytes, buffer has %llu", (unsigned long long)total, (unsigned long long)capacity);
+  unsigned char* b = static_cast<unsigned char*>(bytes);
+  memset(b, 0, total);  // header tail and every pad byte are zero: equal scenes give equal files
+  int32_t head[14] = {0};
+  head[0] = d->abi_version;
+  desc_counts(d, head + 1);
+  memcpy(b, kSceneMagic, 8);
+  memcpy(b + 8, head, sizeof head);
+  SceneSpans s = scene_spans(head + 1);
+  auto put = [&](uint64_t o, const void* src, uint64_t n) { if (n) memcpy(b + o, src, n); };
+  const uint64_t np = d->n_prims, nn = d->n_nodes, nm = d->n_mats, nt = d->n_tex, nq = d->n_perlin, ni = d->n_images;
+  put(s.prim_type, d->prim_type, np * 4); put(s.prim_d, d->prim_d, np * RT_PRIM_STRIDE * 8); put(s.prim_mat, d->prim_mat, np * 4);
+  put(s.node_kind, d->node_kind, nn * 4); put(s.node_i, d->node_i, nn * RT_NODE_ISTRIDE * 4); put(s.node_d, d->node_d, nn * RT_NODE_DSTRIDE * 8);
+  put(s.node_children, d->node_children, (uint64_t)d->n_children * 4);
+  put(s.mat_type, d->mat_type, nm * 4); put(s.mat_d, d->mat_d, nm * RT_MAT_DSTRIDE * 8); put(s.mat_tex, d->mat_tex, nm * 4);
+  put(s.tex_type, d->tex_type, nt * 4); put(s.tex_d, d->tex_d, nt * RT_TEX_DSTRIDE * 8); put(s.tex_i, d->tex_i, nt * RT_TEX_ISTRIDE * 4);
+  put(s.perlin_ranvec, d->perlin_ranvec, nq * 256 * 3 * 8); put(s.perlin_perm, d->perlin_perm, nq * 3 * 256 * 4);
+  put(s.img_w, d->img_w, ni * 4); put(s.img_h, d->img_h, ni * 4);
+  uint64_t o = s.images;
+  for (int i = 0; i < d->n_images; ++i) {
+    const uint64_t n = (uint64_t)d->img_w[i] * (uint64_t)d->img_h[i] * 3u;
+    put(o, d->img_rgb8[i], n);
+    o += pad8(n);
+  }
+  if (written) *written = total;
+  return RT_OK;
+}
+
+int rt_scene_create_from_memory(rt_ctx* ctx, const void* bytes, uint64_t n_bytes, rt_scene** out) {
+  if (!bytes || !out) return fail(RT_ERR_ARG, "scene bytes or out is NULL");
+  try {
+    std::vector<uint64_t> aligned;  // the arrays are read in place, so the blob must sit on an 8-byte boundary
+    const unsigned char* b = static_cast<const unsigned char*>(bytes);
+    if (reinterpret_cast<uintptr_t>(b) & 7u) {
+      aligned.resize((size_t)((n_bytes + 7) / 8));
+      memcpy(aligned.data(), bytes, (size_t)n_bytes);
+      b = reinterpret_cast<const unsigned char*>(aligned.data());
+    }
+    rt_scene_desc d;
+    std::vector<const uint8_t*> imgs;
+    int rc = desc_from_blob(b, n_bytes, &d, imgs);
+    if (rc) return rc;
+    return rt_scene_create(ctx, &d, out);
+  } catch (const std::bad_alloc&) {
+    return fail(RT_ERR_OOM, "out of host memory reading a scene");
+  }
+}
+
+int rt_scene_create_from_file(rt_ctx* ctx, const char* path, rt_scene** out) {
+  if (!path || !out) return fail(RT_ERR_ARG, "scene path or out is NULL");
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(RT_ERR_ARG, "cannot open scene file %s", path);
+  int rc = RT_OK;
+  try {
+    std::vector<uint64_t> buf;
+    long len = -1;
+    if (fseek(f, 0, SEEK_END) == 0) len = ftell(f);
+    if (len < 0 || fseek(f, 0, SEEK_SET) != 0) {
+      rc = fail(RT_ERR_ARG, "cannot size scene file %s", path);
+    } else {
+      buf.resize(((size_t)len + 7) / 8);
+      if (len > 0 && fread(buf.data(), 1, (size_t)len, f) != (size_t)len) rc = fail(RT_ERR_ARG, "short read on scene file %s", path);
+    }
+    fclose(f);
+    f = nullptr;
+    if (rc) return rc;
+    return rt_scene_create_from_memory(ctx, buf.data(), (uint64_t)len, out);
+  } catch (const std::bad_alloc&) {
+    if (f) fclose(f);
+    return fail(RT_ERR_OOM, "out of host memory reading scene file %s", path);
+  }
 }
 
 }  // extern "C"

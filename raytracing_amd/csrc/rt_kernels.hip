@@ -188,13 +188,12 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
   Tally<COUNT> tally;
   if constexpr (COUNT) tally.clear();
 
-  const int npix = R.width * R.height;
 
   // wave-uniform queue window [q_next, q_end) of work items taken from the global queue
   uint32_t q_next = 0, q_end = 0;
   uint32_t q_head = blockIdx.x % RT_QUEUE_HEADS, q_heads_dry = 0;  // the head this wave takes from; heads found empty
   bool q_dry = false;
-  int q_chunk = 0, q_tx0 = 0, q_ty0 = 0, q_s0 = 0, q_s1 = 0;  // what the window's items share
+  int q_tx0 = 0, q_ty0 = 0, q_s0 = 0, q_s1 = 0;  // what the window's items share
 
   // lane state
   bool have_item = false, active = false, done = false;
@@ -282,7 +281,6 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
           const uint32_t rem = base - c * items_per_chunk;
           const int tiles_x = C->R.tiles_x;
           const int tile = C->R.shard_index + (int)(rem >> 6) * C->R.shard_count;
-          q_chunk = (int)c;
           q_tx0 = (tile % tiles_x) * RT_TILE;
           q_ty0 = (tile / tiles_x) * RT_TILE;
           q_s0 = C->R.chunk_start[c];

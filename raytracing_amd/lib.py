@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("RTMI_LIB", os.path.join(_HERE, "librtmi.so"))
 
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version", "rt_scene_create",
            "rt_scene_destroy", "rt_scene_get_info", "rt_render", "rt_render_device",
-           "rt_tonemap_device", "rt_hit_batch", "rt_sample_batch"]
+           "rt_tonemap_device", "rt_hit_batch", "rt_sample_batch", "rt_scene_file_size",
+           "rt_scene_write", "rt_scene_create_from_memory", "rt_scene_create_from_file"]
 
 _LIB = None
 
@@ -60,6 +61,11 @@ def load():
     L.rt_hit_batch.argtypes = [vp, vp, C.c_int32, fp, fp, fp, C.c_float, C.c_float, fp, C.POINTER(abi.rt_hit)]
     L.rt_sample_batch.argtypes = [vp, vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), C.c_int32,
                                   ip, ip, fp]
+    L.rt_scene_file_size.argtypes = [C.POINTER(abi.rt_scene_desc)]
+    L.rt_scene_file_size.restype = C.c_uint64
+    L.rt_scene_write.argtypes = [C.POINTER(abi.rt_scene_desc), vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.rt_scene_create_from_memory.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp)]
+    L.rt_scene_create_from_file.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     _LIB = L
     return L
 
@@ -71,6 +77,19 @@ def _check(rc):
 
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def scene_file_bytes(flat) -> bytes:
+    """The scene file of a FlatScene as the library's own writer produces it (rt_scene_write;
+    needs no device)."""
+    L = load()
+    n = L.rt_scene_file_size(C.byref(flat.desc))
+    if n == 0:
+        raise RtError(abi.RT_ERR_ARG, L.rt_last_error().decode("utf-8", "replace"))
+    buf = (C.c_uint8 * n)()
+    written = C.c_uint64(0)
+    _check(L.rt_scene_write(C.byref(flat.desc), buf, n, C.byref(written)))
+    return bytes(buf[:written.value])
 
 
 def stats_dict(st: abi.rt_stats) -> dict:
@@ -101,6 +120,14 @@ class Context:
     def scene(self, flat) -> "Scene":
         return Scene(self, flat)
 
+    def scene_from_file(self, path: str) -> "Scene":
+        """rt_scene_create_from_file: the library reads and validates the scene file itself."""
+        return Scene(self, None, path=path)
+
+    def scene_from_bytes(self, data: bytes) -> "Scene":
+        """rt_scene_create_from_memory on a scene file held in memory."""
+        return Scene(self, None, data=data)
+
     def tonemap_device(self, d_rgb_sum_ptr: int, n_pixels: int, spp_total: int, d_argb_ptr: int, stream: int = 0):
         _check(self._L.rt_tonemap_device(self._h, d_rgb_sum_ptr, n_pixels, spp_total, d_argb_ptr, stream or None))
 
@@ -108,12 +135,18 @@ class Context:
 class Scene:
     """An uploaded world (rt_scene_create / rt_scene_destroy)."""
 
-    def __init__(self, ctx: Context, flat):
+    def __init__(self, ctx: Context, flat, path: str = None, data: bytes = None):
         self.ctx = ctx
         self.flat = flat
         self._L = ctx._L
         self._h = C.c_void_p()
-        _check(self._L.rt_scene_create(ctx._h, C.byref(flat.desc), C.byref(self._h)))
+        if path is not None:
+            _check(self._L.rt_scene_create_from_file(ctx._h, path.encode(), C.byref(self._h)))
+        elif data is not None:
+            buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+            _check(self._L.rt_scene_create_from_memory(ctx._h, buf, len(data), C.byref(self._h)))
+        else:
+            _check(self._L.rt_scene_create(ctx._h, C.byref(flat.desc), C.byref(self._h)))
 
     def close(self):
         if self._h:

@@ -37,3 +37,28 @@ def test_plain_c_program_renders_the_same_pixels(gpu_ctx, tmp_path):
     top = c_argb[H - 1]  # the PPM's first row is the image's top row = y = H-1
     np.testing.assert_array_equal(body[0, :, 0], (top >> 16) & 255)
     assert f"{W * H * spp} samples" in r.stderr
+
+
+def test_plain_c_program_writes_and_loads_a_scene_file(gpu_ctx, tmp_path):
+    """The same program with a scene-file argument: it writes its hand-built description with
+    rt_scene_write and creates the world from that file. Its pixels must not change, and the file
+    must load through the Python reader into a scene that renders them too."""
+    from raytracing_amd import scenefile
+    from raytracing_amd.core import build_camera
+    W, H, spp = 40, 40, 8
+    raw0, raw1, scn = str(tmp_path / "a.bin"), str(tmp_path / "b.bin"), str(tmp_path / "c.rtscn")
+    env = dict(os.environ)
+    env.pop("LD_LIBRARY_PATH", None)
+    for args in ([raw0], [raw1, scn]):
+        r = subprocess.run([EXE, str(W), str(H), str(spp), str(tmp_path / "x.ppm")] + args, capture_output=True,
+                           text=True, timeout=120, env=env)
+        assert r.returncode == 0, r.stderr
+    a, b = np.fromfile(raw0, dtype=np.uint32), np.fromfile(raw1, dtype=np.uint32)
+    np.testing.assert_array_equal(a, b)
+    flat = scenefile.load(scn)
+    assert flat.desc.n_prims == 18 and flat.desc.n_mats == 4
+    cfg, _, _ = scene_bundle("cornell-box")
+    sc = gpu_ctx.scene(flat)
+    _, argb, _ = sc.render(build_camera(cfg, W / H), abi.make_params(W, H, spp, 50, cfg["background"], seed=0x5EED0001))
+    sc.close()
+    np.testing.assert_array_equal(a, np.asarray(argb, dtype=np.uint32).ravel())

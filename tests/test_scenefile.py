@@ -1,0 +1,113 @@
+"""Scene files: the numpy writer/reader against the library's own writer (no device needed), and
+on the GPU a scene created from a file against the same scene created from the description."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, lib, scenefile
+from raytracing_amd.core import build_camera, setup
+from tests.util import ALL_SCENES, probe_rays
+
+ARRAYS = ["a_prim_type", "a_prim_d", "a_prim_mat", "a_node_kind", "a_node_i", "a_node_d", "a_children",
+          "a_mat_type", "a_mat_d", "a_mat_tex", "a_tex_type", "a_tex_d", "a_tex_i", "a_ranvec", "a_perm",
+          "a_img_w", "a_img_h"]
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_round_trip_and_c_writer_agree(name):
+    """All eight reference worlds: numpy bytes == rt_scene_write bytes, and reading them back gives
+    every array of the description bit for bit."""
+    _, flat = setup(name, 3)
+    data = scenefile.dumps(flat)
+    assert data[:8] == scenefile.MAGIC and len(data) % 8 == 0
+    assert data == lib.scene_file_bytes(flat)
+    back = scenefile.loads(data)
+    for a in ARRAYS:
+        x, y = getattr(flat, a), getattr(back, a)
+        assert x.dtype == y.dtype and x.shape == y.shape and x.tobytes() == y.tobytes(), a
+    assert back.root == flat.root and back.n_media == flat.n_media and len(back.images) == len(flat.images)
+    for x, y in zip(flat.images, back.images):
+        assert x.shape == y.shape and x.tobytes() == y.tobytes()
+    assert scenefile.dumps(back) == data
+
+
+def test_file_size_and_header():
+    _, flat = setup("cornell-box", 1)
+    L = lib.load()
+    n = L.rt_scene_file_size(C.byref(flat.desc))
+    data = scenefile.dumps(flat)
+    assert n == len(data)
+    head = struct.unpack_from("<14i", data, 8)
+    assert head[0] == abi.RTMI_ABI_VERSION and head[1] == 18 and head[10:] == (0, 0, 0, 0)
+    # a buffer that is too small is refused, and nothing is written past it
+    buf = (C.c_uint8 * (n - 8))()
+    assert L.rt_scene_write(C.byref(flat.desc), buf, n - 8, None) == abi.RT_ERR_ARG
+    assert b"needs" in L.rt_last_error()
+    # an invalid description has no file size
+    bad = abi.rt_scene_desc.from_buffer_copy(flat.desc)
+    bad.root = 10 ** 6
+    assert L.rt_scene_file_size(C.byref(bad)) == 0 and b"root" in L.rt_last_error()
+
+
+def test_reader_rejects_malformed_blobs():
+    _, flat = setup("earth", 1)
+    data = scenefile.dumps(flat)
+    with pytest.raises(ValueError):
+        scenefile.loads(b"RTMISCN0" + data[8:])
+    with pytest.raises(ValueError):
+        scenefile.loads(data[:40])
+    with pytest.raises(ValueError):
+        scenefile.loads(data[:len(data) // 2])   # cut inside the image
+    with pytest.raises(ValueError):
+        scenefile.loads(data[:8] + struct.pack("<i", 99) + data[12:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell-box", "earth", "final-scene"])
+def test_scene_from_file_equals_scene_from_description(name, tmp_path):
+    cfg, flat = setup(name, 3)
+    cam = build_camera(cfg, 1.0)
+    path = os.path.join(tmp_path, name + ".rtscn")
+    scenefile.save(flat, path)
+    ctx = lib.Context(0)
+    a = ctx.scene(flat)
+    b = ctx.scene_from_file(path)
+    c = ctx.scene_from_bytes(open(path, "rb").read())
+    assert a.info() == b.info() == c.info()
+    o, d, tm = probe_rays(cfg, 4096, 11)
+    ha, hb, hc = a.hit_batch(o, d, tm), b.hit_batch(o, d, tm), c.hit_batch(o, d, tm)
+    assert ha.tobytes() == hb.tobytes() == hc.tobytes()
+    p = abi.make_params(48, 48, 4, 50, cfg["background"], seed=9)
+    ra, rb = a.render(cam, p)[0], b.render(cam, p)[0]
+    assert np.array_equal(ra, rb, equal_nan=True)
+    for s in (a, b, c):
+        s.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_library_rejects_malformed_scene_files(tmp_path):
+    _, flat = setup("earth", 1)
+    data = scenefile.dumps(flat)
+    ctx = lib.Context(0)
+    cases = {"magic": b"RTMISCN0" + data[8:], "short": data[:40], "cut arrays": data[:200],
+             "cut image": data[:len(data) // 2],
+             "version": data[:8] + struct.pack("<i", 99) + data[12:],
+             "count": data[:12] + struct.pack("<i", -1) + data[16:]}
+    for what, blob in cases.items():
+        with pytest.raises(lib.RtError) as ei:
+            ctx.scene_from_bytes(blob)
+        assert ei.value.code == abi.RT_ERR_ARG, what
+    with pytest.raises(lib.RtError):
+        ctx.scene_from_file(os.path.join(tmp_path, "no-such-file"))
+    # an unaligned buffer is accepted (the library copies it onto an 8-byte boundary)
+    L = lib.load()
+    raw = (C.c_uint8 * (len(data) + 1)).from_buffer_copy(b"\0" + data)
+    h = C.c_void_p()
+    rc = L.rt_scene_create_from_memory(ctx._h, C.byref(raw, 1), len(data), C.byref(h))
+    assert rc == 0 and h
+    L.rt_scene_destroy(h)
+    ctx.close()
