@@ -240,6 +240,11 @@ struct Ctx {
   uint32_t RT_LDS* lds_xch;         // this wave's 1 KiB exchange area (wave_random_in_unit_sphere)
   int* lds_stack;                   // BVH stack base of this lane (stride = blockDim.x)
   int stack_stride;
+#ifdef RT_STAMPS
+  unsigned long long* st_leaf;      // diagnostic build: wave cycles spent in BVH leaf tests,
+  unsigned long long* st_walk;      //   in the walk between them, and the number of leaf rounds
+  unsigned long long* st_rounds;
+#endif
 };
 
 // --------------------------------------------------------------------------- primitives
@@ -454,7 +459,13 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
   const V3 oi = mk(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
   int sp = 0;
   int node = root;
+#ifdef RT_STAMPS
+  unsigned long long st_a, st_b, st_c;
+#endif
   while (node != RT_BVH_DONE) {
+#ifdef RT_STAMPS
+    __builtin_amdgcn_sched_barrier(0); st_a = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
     while ((unsigned)node < (unsigned)RT_BVH_DONE) {  // internal
       const u4 q0 = nodes4[node * 2 + 0];
       const u4 q1 = nodes4[node * 2 + 1];
@@ -482,6 +493,9 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
         node = RT_BVH_DONE;
       }
     }
+#ifdef RT_STAMPS
+    __builtin_amdgcn_sched_barrier(0); st_b = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
     if (node != RT_BVH_DONE) {  // a leaf
       test_prim_any_order<X>(S, ~node, r, tmin, best, tally);
       if (sp > 0) {
@@ -491,6 +505,11 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
         node = RT_BVH_DONE;
       }
     }
+#ifdef RT_STAMPS
+    __builtin_amdgcn_sched_barrier(0); st_c = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+    // (per-lane sums of wave-level times: the reader takes the maximum over the wave's lanes = the lane that stayed longest)
+    if (ctx.st_leaf) { *ctx.st_walk += st_b - st_a; *ctx.st_leaf += st_c - st_b; *ctx.st_rounds += 1; }
+#endif
   }
 }
 

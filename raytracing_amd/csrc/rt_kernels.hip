@@ -84,6 +84,9 @@ __device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* ld
   const size_t xch_bytes = (size_t)(blockDim.x >> 6) * 1024;
   X.lds_stack = reinterpret_cast<int*>(lds + vec_bytes + perm_bytes + info_bytes + xch_bytes) + threadIdx.x;
   X.stack_stride = blockDim.x;
+#ifdef RT_STAMPS
+  X.st_leaf = X.st_walk = X.st_rounds = nullptr;
+#endif
   return X;
 }
 
@@ -182,6 +185,10 @@ template <uint32_t FEAT, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_render(RenderArgs A) {
   extern __shared__ __align__(16) unsigned char lds[];
   Ctx<FEAT> X = make_ctx<FEAT>(A.S, lds);
+#ifdef RT_STAMPS
+  unsigned long long c_leaf = 0, c_walk = 0, c_rounds = 0;
+  X.st_leaf = &c_leaf; X.st_walk = &c_walk; X.st_rounds = &c_rounds;
+#endif
   const DRender& R = A.R;
   float* __restrict__ out = A.out;
   unsigned long long* __restrict__ stats = A.stats;
@@ -362,7 +369,25 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       // The instantiations that walk a BVH lose more to the extra live state than the shared draw
       // saves: there each lane runs ray-color on its own.
       n_rays += (unsigned long long)__popcll(__ballot(active));
+#ifdef RT_STAMPS
+      {  // the same as path_step below, with the phases stamped
+        Rec rec;
+        rec.mtype = -1;
+        bool hit = false;
+        if (active) hit = closest_hit(X, ray, 0.001f, __builtin_inff(), g, bounce, nullptr, false, false, rec, tally, &tsi);
+        RT_STAMP(ts3);
+        if (active) {
+          V3 L;
+          if (path_finish<false>(X, R, hit, rec, mk(0.f, 0.f, 0.f), ray, beta, bounce, g, L, tally)) {
+            acc = acc + L;
+            active = false;
+          }
+        }
+      }
+      if (false) {
+#else
       if (active) {
+#endif
         V3 L;
         if (path_step(X, R, ray, beta, bounce, g, L, tally)) {
           acc = acc + L;  // core.clj:120
@@ -384,6 +409,14 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
     atomicMax(&stats[2 + 6], c_iters);                       // iterations of the busiest wave
     atomicMax(&stats[2 + 7], ~0ull - c_iters);               // ... and (inverted) of the idlest
     atomicAdd(&stats[2 + 8], c_iters * c_iters);             // for the spread
+  }
+  {  // BVH walk: the wave's time is that of the lane that stayed in each walk longest
+    unsigned long long w = c_walk, l = c_leaf, r = c_rounds;
+    for (int off = 32; off >= 1; off >>= 1) {
+      unsigned long long w2 = __shfl_xor(w, off, 64), l2 = __shfl_xor(l, off, 64), r2 = __shfl_xor(r, off, 64);
+      w = w2 > w ? w2 : w; l = l2 > l ? l2 : l; r = r2 > r ? r2 : r;
+    }
+    if (lane == 0) { atomicAdd(&stats[2 + 9], w); atomicAdd(&stats[2 + 10], l); atomicAdd(&stats[2 + 11], r); }
   }
 #endif
   // One atomic per wave and counter, not per lane: half a million same-address atomics at the end

@@ -23,6 +23,9 @@ for name, v in (("queue/flush", q), ("camera regen", c), ("closest_hit", h), ("s
     print(f"  {name:14s} {v / it:9.1f} cycles per wave-iteration  {100 * v / tot:5.1f} %")
 print(f"  total          {tot / it:9.1f}")
 print(f"  of closest_hit: group loops {grp / it:9.1f}, record + unwind {(h - grp) / it:9.1f}")
+if ev[11]:
+    print(f"  of group loops: BVH walk {ev[9] / it:9.1f}, BVH leaf tests {ev[10] / it:9.1f} (longest lane of each wave); "
+          f"leaf rounds per wave-iteration {ev[11] / it:.2f}")
 mx, mn_inv, sq = ev[6], ev[7], ev[8]
 if mx:
     import math
