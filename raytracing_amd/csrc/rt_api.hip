@@ -514,14 +514,38 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
       std::memset(&G, 0, sizeof G);
       G.chain = chain; G.first_prim = (int)prims.size(); G.bvh_root = -1;
       chain_motion(chain, G, H);
+      // A sphere with the centre and radius of an EARLIER sphere of the same scan can never be the
+      // closest hit: it computes the same two roots, its range is the earlier one's or narrower
+      // (closest-so-far only shrinks), and base.clj:242,248 need root < t-max strictly, so it loses the
+      // tie where the earlier one hit and misses where that one missed. (The random-spheres world lists
+      // two coincident r = 1000 ground spheres, scenes.clj:52,64.) Such spheres keep their records at
+      // the end of the group but are left out of its tested range.
+      size_t n_tested = list.size();
+      {
+        std::map<std::array<double, 4>, int> seen;
+        std::vector<int> kept, shadowed;
+        for (int pi : list) {
+          bool dup = false;
+          if (d->prim_type[pi] == RT_PRIM_SPHERE) {
+            const double* pd = d->prim_d + (size_t)pi * RT_PRIM_STRIDE;
+            dup = !seen.emplace(std::array<double, 4>{pd[0], pd[1], pd[2], pd[3]}, pi).second;
+          }
+          (dup ? shadowed : kept).push_back(pi);
+        }
+        n_tested = kept.size();
+        list = kept;
+        list.insert(list.end(), shadowed.begin(), shadowed.end());
+      }
+      size_t li = 0;
       for (int pi : list) {
+        const bool tested = li++ < n_tested;
         DPrim P;
         std::memset(&P, 0, sizeof P);
         const int ptype = d->prim_type[pi];
         P.type = ptype | ((int)groups.size() << 4);
         P.mat = d->prim_mat[pi];
         const double* pd = d->prim_d + (size_t)pi * RT_PRIM_STRIDE;
-        if (ptype <= RT_PRIM_MOVING_SPHERE) { features |= F_SPHERES; G.n_sph++; }
+        if (ptype <= RT_PRIM_MOVING_SPHERE) { features |= F_SPHERES; G.n_sph += tested ? 1 : 0; }
         if (ptype <= RT_PRIM_MOVING_SPHERE && chain != 0) G.flags |= DGROUP_SPHERES_UNDER_CHAIN;
         if (ptype == RT_PRIM_XY_RECT) G.n_xy++;
         if (ptype == RT_PRIM_XZ_RECT) G.n_xz++;
@@ -540,7 +564,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
       }
       G.first_rect = (int)(brute_rects.size() / RT_PAIR_STRIDE);
       G.first_box = (int)(brute_boxes.size() / RT_BOX_STRIDE);
-      if ((int)list.size() <= RT_BRUTE_MAX) {
+      if ((int)n_tested <= RT_BRUTE_MAX) {
         // Six rects that close an axis-aligned box with one material (what box.clj:7-20 builds) are
         // intersected as one slab test; they keep their primitive records and indices.
         const int o_xy = G.first_prim, o_xz = o_xy + G.n_xy, o_yz = o_xz + G.n_xz, o_end = o_yz + G.n_yz;

@@ -273,8 +273,22 @@ RT_DEV RayX make_rayx(V3 o, V3 d, float tm) {
   r.o_lo = r.d_lo = mk(0.f, 0.f, 0.f);
   return r;
 }
-RT_DEV D3 rayx_o64(const RayX& r) { return mkd((double)r.o.x + (double)r.o_lo.x, (double)r.o.y + (double)r.o_lo.y, (double)r.o.z + (double)r.o_lo.z); }
-RT_DEV D3 rayx_d64(const RayX& r) { return mkd((double)r.d.x + (double)r.d_lo.x, (double)r.d.y + (double)r.d_lo.y, (double)r.d.z + (double)r.d_lo.z); }
+// LO = false where the residuals are known to be zero (instantiations without chains): x + 0.0 is
+// not x for x = -0.0, so the compiler would keep those additions.
+template <bool LO>
+RT_DEV D3 rayx_o64(const RayX& r) {
+  if constexpr (!LO) return tod(r.o);
+  else return mkd((double)r.o.x + (double)r.o_lo.x, (double)r.o.y + (double)r.o_lo.y, (double)r.o.z + (double)r.o_lo.z);
+}
+template <bool LO>
+RT_DEV D3 rayx_d64(const RayX& r) {
+  if constexpr (!LO) return tod(r.d);
+  else return mkd((double)r.d.x + (double)r.d_lo.x, (double)r.d.y + (double)r.d_lo.y, (double)r.d.z + (double)r.d_lo.z);
+}
+// How an instantiation intersects spheres (template argument of sphere_roots / sphere_t).
+enum { SPH_ONE_RCP = 1, SPH_LO = 2 };
+template <class X>
+constexpr int sphere_mode() { return (X::has(F_NOISE) ? 0 : SPH_ONE_RCP) | (X::has(F_CHAINS) ? SPH_LO : 0); }
 
 // rectangles.clj:20-30 (XY), :57-67 (XZ), :94-104 (YZ): t from the constant axis, reject iff
 // t < t-min or t > t-max (so equality with the closest-so-far is accepted and a later rect
@@ -302,15 +316,27 @@ RT_DEV D3 sphere_center(const PRIM& P, int type, float tm) {
 template <class PRIM>
 RT_DEV double sphere_radius(const PRIM& P, int type) { return type == RT_PRIM_SPHERE ? P.d[3] : P.d[8]; }
 
+// n / d in FP64, correctly rounded, given r = RN(1/d) (Markstein): q = RN(n r), then one FMA
+// residual and one FMA correction. Three instructions instead of the ~12 of a full division;
+// d = 0 takes the real division and its IEEE result.
+RT_DEV double exact_div(double n, double d, double r) {
+  if (d == 0.0) return n / d;
+  double q = n * r;
+  return fma(fma(-q, d, n), r, q);
+}
+
 // base.clj:234-241,247 / :274-281,287 in FP64: both candidate roots. The second candidate is
 // (-half_b + root1) / a, as the reference computes it (it adds the first root, not
 // sqrt(discriminant)). False when the discriminant is not positive.
-template <class PRIM, class T>
+// SPH_ONE_RCP: both roots from one reciprocal of a and two corrected products (same values; fewer
+// instructions, two more live registers — the all-features kernels keep the two divisions).
+// SPH_LO: the ray carries FP64 residuals.
+template <int MODE, class PRIM, class T>
 RT_DEV bool sphere_roots(const PRIM& P, int type, const RayX& r, double& root1, double& root2, T& tally) {
   if (type == RT_PRIM_MOVING_SPHERE) tally.template add<RT_EV_MSPHERE_CENTER>();
   D3 c = sphere_center(P, type, r.tm);
   double radius = sphere_radius(P, type);
-  D3 o = rayx_o64(r), d = rayx_d64(r);
+  D3 o = rayx_o64<(MODE & SPH_LO) != 0>(r), d = rayx_d64<(MODE & SPH_LO) != 0>(r);
   D3 oc = mkd(o.x - c.x, o.y - c.y, o.z - c.z);
   double a = ddot(d, d);
   double half_b = ddot(oc, d);
@@ -319,18 +345,24 @@ RT_DEV bool sphere_roots(const PRIM& P, int type, const RayX& r, double& root1, 
   tally.template add<RT_EV_SPHERE_TEST>();
   if (!(disc > 0.0)) return false;
   double sqrtd = sqrt(disc);
-  root1 = (-half_b - sqrtd) / a;
-  root2 = (-half_b + root1) / a;
+  if constexpr ((MODE & SPH_ONE_RCP) != 0) {
+    const double ra = 1.0 / a;
+    root1 = exact_div(-half_b - sqrtd, a, ra);
+    root2 = exact_div(-half_b + root1, a, ra);
+  } else {
+    root1 = (-half_b - sqrtd) / a;
+    root2 = (-half_b + root1) / a;
+  }
   return true;
 }
 
 // The range tests of base.clj:242,248: t_min < root (FP64) and (float)root < t_max (strict, so
 // the earlier of two coincident spheres keeps an exact tie).
-template <class PRIM, class T>
+template <int MODE, class PRIM, class T>
 RT_DEV bool sphere_t(const PRIM& P, int type, const RayX& r, double tmin, float tmax, float& t_out, double& root_out,
                      T& tally) {
   double root1, root2;
-  if (!sphere_roots(P, type, r, root1, root2, tally)) return false;
+  if (!sphere_roots<MODE>(P, type, r, root1, root2, tally)) return false;
   tally.template add<RT_EV_SPHERE_ROOT>();
   if (root1 > tmin && (float)root1 < tmax) { t_out = (float)root1; root_out = root1; return true; }
   tally.template add<RT_EV_SPHERE_ROOT>();
@@ -373,7 +405,7 @@ RT_DEV void test_prim_any_order(const DScene& S, int idx, const RayX& r, float t
     }
   } else {
     if constexpr (X::has(F_SPHERES)) {
-      if (!sphere_t(P, type, r, (double)tmin, __builtin_inff(), t, root, tally)) return;
+      if (!sphere_t<sphere_mode<X>()>(P, type, r, (double)tmin, __builtin_inff(), t, root, tally)) return;
       if (t > best.t) return;
       if (t == best.t) {
         if (best.prim < 0) return;  // t == t_max with nothing hit yet: the strict test fails
@@ -665,7 +697,7 @@ RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best
         const DPrim RT_CONST& P = prims[first + i];
         float t = 0.f;
         double root = 0.0;
-        bool ok = sphere_t(P, prim_type(P.type), r, (double)tmin, best.t, t, root, tally);
+        bool ok = sphere_t<sphere_mode<X>()>(P, prim_type(P.type), r, (double)tmin, best.t, t, root, tally);
         best.t = ok ? t : best.t;
         best.prim = ok ? first + i : best.prim;
         best.root = ok ? root : best.root;
@@ -751,7 +783,7 @@ RT_DEV void prim_record(const DScene& S, int prim, const DPrimInfo& I, const Ray
       const DPrim RT_CONST& P = cptr(S.prims)[prim];
       D3 c = sphere_center(P, type, r.tm);
       double inv_r = 1.0 / sphere_radius(P, type);
-      D3 o64 = rayx_o64(r), d64 = rayx_d64(r);
+      D3 o64 = rayx_o64<X::has(F_CHAINS)>(r), d64 = rayx_d64<X::has(F_CHAINS)>(r);
       D3 pd = mkd(fma(root, d64.x, o64.x), fma(root, d64.y, o64.y), fma(root, d64.z, o64.z));
       D3 out = mkd((pd.x - c.x) * inv_r, (pd.y - c.y) * inv_r, (pd.z - c.z) * inv_r);
       if (want_uv) sphere_uv(out, rec.u, rec.v);
@@ -827,7 +859,7 @@ RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax,
       const RayX r = group_ray<X>(S, first_group, G.flags, G.rc, G.rs, G.bx, G.by, G.bz, wr, tally);
       const DPrim RT_CONST& P = cptr(S.prims)[G.first_prim];
       double root1, root2;
-      if (!sphere_roots(P, prim_type(P.type), r, root1, root2, tally)) return false;
+      if (!sphere_roots<sphere_mode<X>()>(P, prim_type(P.type), r, root1, root2, tally)) return false;
       const double NINF = -(double)INF;
       if (root1 > NINF && (float)root1 < INF) b1.t = (float)root1;
       else if (root2 > NINF && (float)root2 < INF) b1.t = (float)root2;
@@ -1137,16 +1169,8 @@ RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t
 }
 
 // --------------------------------------------------------------------------------- camera
-// core.clj:96-102 + ray.clj:14-26 in FP64 (once per path), rounded to the FP32 path state.
-// n / d in FP64, correctly rounded, given r = RN(1/d) (Markstein): q = RN(n r), then one FMA
-// residual and one FMA correction. Three instructions instead of the ~12 of a full division;
-// d = 0 (a one-pixel-wide image) takes the real division and its IEEE result.
-RT_DEV double exact_div(double n, double d, double r) {
-  if (d == 0.0) return n / d;
-  double q = n * r;
-  return fma(fma(-q, d, n), r, q);
-}
-
+// core.clj:96-102 + ray.clj:14-26 in FP64 (once per path), rounded to the FP32 path state
+// (the divisions by W-1 and H-1 through exact_div and the reciprocals the host rounded).
 // `camp` points at a DCamera in any address space (the kernarg segment for the render kernel).
 template <class CAMP, class T>
 RT_DEV Ray camera_ray(CAMP camp, int x, int y, const Rng& g, T& tally) {
