@@ -489,6 +489,11 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
   const V3 inv = mk(__builtin_amdgcn_fmed3f(r.inv.x, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(r.inv.y, -1e30f, 1e30f),
                     __builtin_amdgcn_fmed3f(r.inv.z, -1e30f, 1e30f));
   const V3 oi = mk(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
+  // The node table's address stays in registers across the walk (the register allocator would
+  // otherwise re-read it from the kernel arguments, a scalar-memory round trip, in every step).
+  asm volatile("" : "+s"(nodes4));
+  // The stack index is kept as an element offset (entry i of this lane is lds_stack[i * stride]).
+  const int stride = ctx.stack_stride;
   int sp = 0;
   int node = root;
 #ifdef RT_STAMPS
@@ -513,14 +518,14 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
       const bool hr = slab16(a3.x, a3.y, a4.x, a4.y, a5.x, a5.y, inv, oi, tmin, best.t, tr);
       if (hl && hr) {
         const bool swap = tr < tl;
-        ctx.lds_stack[sp * ctx.stack_stride] = swap ? left : right;
-        ++sp;
+        ctx.lds_stack[sp] = swap ? left : right;
+        sp += stride;
         node = swap ? right : left;
       } else if (hl || hr) {
         node = hl ? left : right;
       } else if (sp > 0) {
-        --sp;
-        node = ctx.lds_stack[sp * ctx.stack_stride];
+        sp -= stride;
+        node = ctx.lds_stack[sp];
       } else {
         node = RT_BVH_DONE;
       }
@@ -531,8 +536,8 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
     if (node != RT_BVH_DONE) {  // a leaf
       test_prim_any_order<X>(S, ~node, r, tmin, best, tally);
       if (sp > 0) {
-        --sp;
-        node = ctx.lds_stack[sp * ctx.stack_stride];
+        sp -= stride;
+        node = ctx.lds_stack[sp];
       } else {
         node = RT_BVH_DONE;
       }

@@ -1,5 +1,7 @@
 """Throughput of the path kernel on every reference world at its full benchmark size
-(reduced spp): Msamples/s, rays/sample, kernel ms. Usage: python tools/scene_bench.py [scene ...]"""
+(reduced spp): Msamples/s, rays/sample, kernel ms. Usage: python tools/scene_bench.py [--full] [scene ...]
+--full: the sample counts of the benchmark configurations (random-scene @500, the texture worlds and the
+Cornell boxes @1000; final-scene @100 of its 10 000, one GPU's share of a sample split being 1 250)."""
 import sys
 from raytracing_amd import abi, lib
 from raytracing_amd.core import build_camera, setup
@@ -14,10 +16,15 @@ CASES = {  # scene -> (W, H, spp)
     "simple-light": (1024, 1024, 16),
     "final-scene": (3840, 2160, 4),
 }
-names = sys.argv[1:] or list(CASES)
+FULL = {"cornell-box": 1000, "cornell-smoke": 1000, "random-scene": 500, "two-spheres": 1000,
+        "two-perlin-spheres": 1000, "earth": 1000, "simple-light": 1000, "final-scene": 100}
+full = "--full" in sys.argv[1:]
+names = [a for a in sys.argv[1:] if a != "--full"] or list(CASES)
 ctx = lib.Context(0)
 for name in names:
     W, H, spp = CASES[name]
+    if full:
+        spp = FULL[name]
     cfg, flat = setup(name, 1)
     cam = build_camera(cfg, W / H)
     sc = ctx.scene(flat)
@@ -25,7 +32,7 @@ for name in names:
     sc.render_device(cam, p, 0, 0, want_stats=True)  # warm-up
     st = sc.render_device(cam, p, 0, 0, want_stats=True)
     ms = st["kernel_ms"]
-    print(f"{name:20s} {W}x{H} @{spp:3d}: kernel {ms:9.2f} ms  {W * H * spp / ms / 1e3:9.1f} Msamples/s  "
+    print(f"{name:20s} {W}x{H} @{spp:4d}: kernel {ms:9.2f} ms  {W * H * spp / ms / 1e3:9.1f} Msamples/s  "
           f"{st['rays'] / ms / 1e3:9.1f} Mrays/s  rays/sample {st['rays'] / st['samples']:6.2f}  info {sc.info()}", flush=True)
     sc.close()
 ctx.close()
