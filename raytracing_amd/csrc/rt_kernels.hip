@@ -22,7 +22,7 @@
 #define RT_WAVES_SPH 5
 #endif
 #ifndef RT_WAVES_ALL
-#define RT_WAVES_ALL 3
+#define RT_WAVES_ALL 4
 #endif
 #ifndef RT_WAVES_DEEP
 #define RT_WAVES_DEEP 4
@@ -153,8 +153,9 @@ __device__ __forceinline__ bool path_step(const XC& X, const DRender& R, Ray& ra
 // the whole file): the lean instantiations are latency-bound on scalar loads and the RNG's
 // integer multiplies, which more resident waves hide.
 constexpr int waves_per_simd(uint32_t feat, bool count) {
-  // the all-features kernel wants 211 registers; squeezing it costs a few spills but the long BVH
-  // walks gain more from a third and fourth wave than the texture worlds lose
+  // the all-features kernel fits 128 registers with 26 spilled (the FP64 arccosine and arctangent of
+  // the sphere u/v once made it want 211): four waves measured 9 % faster than three on the texture
+  // worlds, five 20 % slower everywhere (F_DEEP is the same code under a knob of its own)
   if (feat & F_NOISE) return count ? 2 : ((feat & F_DEEP) ? RT_WAVES_DEEP : RT_WAVES_ALL);
   if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : RT_WAVES_SPH;
   // the smoke worlds' kernel spills at 72 and at 80 registers: five waves measured 5 % faster than seven
