@@ -288,7 +288,7 @@ RT_DEV D3 rayx_d64(const RayX& r) {
 // How an instantiation intersects spheres (template argument of sphere_roots / sphere_t).
 enum { SPH_ONE_RCP = 1, SPH_LO = 2 };
 template <class X>
-constexpr int sphere_mode() { return (X::has(F_NOISE) ? 0 : SPH_ONE_RCP) | (X::has(F_CHAINS) ? SPH_LO : 0); }
+constexpr int sphere_mode() { return SPH_ONE_RCP | (X::has(F_CHAINS) ? SPH_LO : 0); }
 
 // rectangles.clj:20-30 (XY), :57-67 (XZ), :94-104 (YZ): t from the constant axis, reject iff
 // t < t-min or t > t-max (so equality with the closest-so-far is accepted and a later rect
@@ -328,8 +328,8 @@ RT_DEV double exact_div(double n, double d, double r) {
 // base.clj:234-241,247 / :274-281,287 in FP64: both candidate roots. The second candidate is
 // (-half_b + root1) / a, as the reference computes it (it adds the first root, not
 // sqrt(discriminant)). False when the discriminant is not positive.
-// SPH_ONE_RCP: both roots from one reciprocal of a and two corrected products (same values; fewer
-// instructions, two more live registers — the all-features kernels keep the two divisions).
+// SPH_ONE_RCP: both roots from one reciprocal of a and two corrected products (same values, fewer
+// instructions, two more live registers).
 // SPH_LO: the ray carries FP64 residuals.
 template <int MODE, class PRIM, class T>
 RT_DEV bool sphere_roots(const PRIM& P, int type, const RayX& r, double& root1, double& root2, T& tally) {
