@@ -653,6 +653,15 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
       dm.neg_inv_density = M.neg_inv_density;
     }
     dm.n_groups = (int)groups.size() - dm.first_group;  // 0 for a medium the root never reaches
+    if (dm.n_groups > 0) {
+      // the two boundary shapes medium_t answers from one intersection (every medium the reference
+      // ships); anything else needs an instantiation with the general boundary loops
+      const DGroup& B = groups[(size_t)dm.first_group];
+      const int n_rects = B.n_xy + B.n_xz + B.n_yz;
+      const bool one_sphere = dm.n_groups == 1 && B.n_sph == 1 && n_rects == 0;
+      const bool one_box = dm.n_groups == 1 && B.n_sph == 0 && n_rects <= RT_BRUTE_MAX && B.loose == (1 << 24);
+      if (!one_sphere && !one_box) features |= F_MEDIA_ANY;
+    }
     {  // an empty group that carries the motion of the chain the medium itself lives under
       DGroup G;
       DGroup64 H;

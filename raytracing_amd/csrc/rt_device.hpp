@@ -903,10 +903,16 @@ RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax,
     }
   }
   if (!single_sphere && !single_box) {
-    for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, -INF, b1, tally);
-    if (b1.prim < 0) return false;
-    for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, b1.t + 0.0001f, b2, tally);
-    if (b2.prim < 0) return false;
+    // any other boundary: two closest-hit queries over its groups. Only the instantiations for
+    // worlds that have such a medium carry these loops (the host sets F_MEDIA_ANY).
+    if constexpr (X::has(F_MEDIA_ANY)) {
+      for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, -INF, b1, tally);
+      if (b1.prim < 0) return false;
+      for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, b1.t + 0.0001f, b2, tally);
+      if (b2.prim < 0) return false;
+    } else {
+      return false;  // a medium the root never reaches (no boundary groups)
+    }
   }
   float t1 = (b1.t < tmin) ? tmin : b1.t;
   float t2 = (b2.t > tmax) ? tmax : b2.t;

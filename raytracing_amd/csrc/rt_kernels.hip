@@ -466,7 +466,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hit_batch(DScene S, int n, const f
                                                         const float* __restrict__ time, float tmin, float tmax,
                                                         const float* __restrict__ medium_xi, rt_hit* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char lds[];
-  Ctx<F_ALL> X = make_ctx<F_ALL>(S, lds);
+  Ctx<F_ALL | F_MEDIA_ANY> X = make_ctx<F_ALL | F_MEDIA_ANY>(S, lds);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Ray r{mk(orig3[3 * i], orig3[3 * i + 1], orig3[3 * i + 2]), mk(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]),
@@ -518,15 +518,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_sample_batch(DScene S, DCamera cam
 //   V_SMOKE  + constant media with isotropic phase functions (the Cornell smoke box)
 //   V_SPH    spheres and rects at the top level, BVHs, metal / dielectric, checker and image
 //            textures: everything of the first book (the random-spheres world, the earth)
-//   V_ALL    everything
+//   V_ALL    everything the reference's worlds use
+//   V_FULL   + media whose boundary is any hittable (V_ALL answers one-sphere and one-box boundaries)
 constexpr uint32_t V_RECT = F_CHAINS | F_SMALL;
 constexpr uint32_t V_SMOKE = F_CHAINS | F_MEDIA | F_SMALL;
 constexpr uint32_t V_SPH = F_SPHERES | F_BVH | F_SPECULAR | F_TEXTURES;
 constexpr uint32_t V_ALL = F_ALL;
 constexpr uint32_t V_ALL_DEEP = F_ALL | F_DEEP;  // everything, for worlds with BVHs
+constexpr uint32_t V_FULL = F_ALL | F_MEDIA_ANY;
 
 int pick_variant(const DScene& S) {
   const bool small = S.n_prims <= RT_LDS_PRIMS && S.n_chains <= RT_LDS_CHAINS;
+  if (S.features & F_MEDIA_ANY) return 5;
   if (small && (S.features & ~V_RECT) == 0) return 0;
   if (small && (S.features & ~V_SMOKE) == 0) return 1;
   if ((S.features & ~V_SPH) == 0) return 2;
@@ -552,7 +555,9 @@ auto with_render_kernel(const DScene& S, bool count, F&& f) {
     case 6: return f(k_render<V_ALL, false>);
     case 7: return f(k_render<V_ALL, true>);
     case 8: return f(k_render<V_ALL_DEEP, false>);
-    default: return f(k_render<V_ALL, true>);
+    case 9: return f(k_render<V_ALL, true>);
+    case 10: return f(k_render<V_FULL, false>);
+    default: return f(k_render<V_FULL, true>);
   }
 }
 
@@ -602,6 +607,7 @@ hipError_t launch_sample_batch(const DScene& S, const DCamera& cam, const DRende
     case 0: hipLaunchKernelGGL(k_sample_batch<V_RECT>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     case 1: hipLaunchKernelGGL(k_sample_batch<V_SMOKE>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     case 2: hipLaunchKernelGGL(k_sample_batch<V_SPH>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
+    case 5: hipLaunchKernelGGL(k_sample_batch<V_FULL>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     default: hipLaunchKernelGGL(k_sample_batch<V_ALL>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
   }
   return hipGetLastError();

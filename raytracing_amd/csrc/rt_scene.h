@@ -41,7 +41,9 @@ enum : uint32_t {
   F_NOISE = 128,    // Perlin noise textures: tables in LDS, by far the most registers
   F_IMAGE = 256,    // image textures: the only consumers of u/v (FP64 acos/atan2 for spheres)
   F_ALL = 63 | 128 | 256,
-  F_DEEP = 512      // not a scene feature: same code, compiled for more waves per SIMD (BVH worlds)
+  F_DEEP = 512,     // not a scene feature: same code, compiled for more waves per SIMD (BVH worlds)
+  F_MEDIA_ANY = 1024  // some medium's boundary is neither one sphere nor one closed box: its two boundary
+                      // queries run the general group loops (30 more registers in every kernel that has them)
 };
 
 // 80 bytes. Spheres are intersected in FP64 (|oc|^2 - r^2 cancels catastrophically in FP32 for
