@@ -227,7 +227,9 @@ int rt_tonemap_device(rt_ctx* ctx, const float* d_rgb_sum, int32_t n_pixels, int
 /* Parity hook: closest hit for a batch of rays exactly as ray-color's `hit` call would
  * return it (core.clj:23). orig3/dir3: n*3 floats, time: n floats (NULL = 0).
  * medium_xi: n * n_media scripted uniforms for the free-flight draw of each medium
- * (constant_medium.clj:32), or NULL to skip MEDIUM nodes. Host buffers. */
+ * (constant_medium.clj:32), or NULL to skip MEDIUM nodes. Host buffers.
+ * t_min < 0 is refused (RT_ERR_UNSUPPORTED) for worlds that list the same sphere twice: the
+ * duplicate is left out of the scan, which is exact only for t_min >= 0 (ray-color asks 0.001). */
 int rt_hit_batch(rt_ctx* ctx, const rt_scene* scene, int32_t n, const float* orig3,
                  const float* dir3, const float* time, float t_min, float t_max,
                  const float* medium_xi, rt_hit* out);

@@ -70,6 +70,7 @@ struct rt_scene {
   bool has_time_bounds = false;
   float time_lo = 0.f, time_hi = 1.f;
   int blocks_per_cu[2] = {0, 0};  // occupancy of k_render<false>, k_render<true>
+  int n_shadowed_spheres = 0;     // duplicates left out of their groups' tested ranges (exact for t-min >= 0)
 };
 
 namespace {
@@ -476,6 +477,8 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
     return e;
   };
   std::function<void(int, std::vector<int>)> emit_one;
+  bool drop_shadowed_spheres = true;  // surface groups; switched off while media boundaries are emitted
+  int n_shadowed_total = 0;
   auto emit_groups = [&](const Sink& sink) {
     for (int chain : sink.chain_order) {
       std::vector<int> list = sink.prims.at(chain);
@@ -519,9 +522,12 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
       // (closest-so-far only shrinks), and base.clj:242,248 need root < t-max strictly, so it loses the
       // tie where the earlier one hit and misses where that one missed. (The random-spheres world lists
       // two coincident r = 1000 ground spheres, scenes.clj:52,64.) Such spheres keep their records at
-      // the end of the group but are left out of its tested range.
+      // the end of the group but are left out of its tested range. That holds for t-min >= 0 only: with a
+      // first root below zero the duplicate's second root (-half_b + root1) / a can come out SMALLER
+      // than the first and win, so the boundary groups of media, which are asked over (-inf, inf)
+      // (constant_medium.clj:12), keep their duplicates.
       size_t n_tested = list.size();
-      {
+      if (drop_shadowed_spheres) {
         std::map<std::array<double, 4>, int> seen;
         std::vector<int> kept, shadowed;
         for (int pi : list) {
@@ -533,6 +539,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
           (dup ? shadowed : kept).push_back(pi);
         }
         n_tested = kept.size();
+        n_shadowed_total += (int)shadowed.size();
         list = kept;
         list.insert(list.end(), shadowed.begin(), shadowed.end());
       }
@@ -647,7 +654,9 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
     std::memset(&dm, 0, sizeof dm);
     dm.first_group = (int)groups.size();
     if (M.present) {
+      drop_shadowed_spheres = false;
       emit_groups(M.boundary);
+      drop_shadowed_spheres = true;
       dm.outer_chain = M.outer_chain;
       dm.phase_mat = M.phase_mat;
       dm.neg_inv_density = M.neg_inv_density;
@@ -791,6 +800,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   sc->ctx = ctx;
   sc->n_media = d->n_media;
   sc->has_time_bounds = any_moving;
+  sc->n_shadowed_spheres = n_shadowed_total;
   sc->time_lo = (float)tlo;
   sc->time_hi = (float)thi;
   struct Guard {
@@ -976,6 +986,9 @@ int rt_hit_batch(rt_ctx* ctx, const rt_scene* sc, int32_t n, const float* orig3,
   if (!ctx || !sc || sc->ctx != ctx) return fail(RT_ERR_ARG, "ctx/scene is NULL or the scene belongs to another context");
   if (n < 0 || (n > 0 && (!orig3 || !dir3 || !out))) return fail(RT_ERR_ARG, "bad ray batch arguments");
   if (n == 0) return RT_OK;
+  if (t_min < 0.f && sc->n_shadowed_spheres > 0)
+    return fail(RT_ERR_UNSUPPORTED, "t_min < 0 with %d coincident duplicate sphere(s) in the world: they are left out of the "
+                "scan, which is only exact for t_min >= 0", sc->n_shadowed_spheres);
   if (sc->has_time_bounds) {
     for (int i = 0; i < n; ++i) {
       float t = time ? time[i] : 0.f;

@@ -72,3 +72,44 @@ def test_shutter_outside_moving_sphere_bounds_is_rejected(gpu_ctx):
     with pytest.raises(lib.RtError):
         sc.render(cam, abi.make_params(8, 8, 1))
     sc.close()
+
+
+def test_duplicate_spheres(gpu_ctx, oracle):
+    """The same sphere listed twice (scenes.clj:52,64 does it with the ground of random-scene): the
+    later copy can never be the closest hit for t_min >= 0 and is left out of the device's scan, so
+    records must still equal the oracle's, which scans both; a negative t_min, where that argument
+    fails, is refused. As the boundary of a medium, which is asked over (-inf, inf)
+    (constant_medium.clj:12), the copies are both kept: rays that start beyond the boundary have a
+    negative first root there, and the second copy's second root can then win."""
+    from test_gpu_parity import _check_hits
+    a, b = lambertian([0.8, 0.2, 0.2]), lambertian([0.2, 0.2, 0.8])
+    world = [sphere([0, 0, 0], 2, a), sphere([5, 0, 0], 1, GREY), sphere([0, 0, 0], 2, b)]
+    flat = flatten.flatten_world(world)
+    sc = gpu_ctx.scene(flat)
+    rng = np.random.default_rng(4)
+    n = 8000
+    o = rng.uniform(-6, 8, (n, 3)).astype(np.float32)
+    o[: n // 3] = rng.uniform(-1.2, 1.2, (n // 3, 3)).astype(np.float32)  # inside the double sphere
+    d = (rng.normal(size=(n, 3)) * rng.uniform(0.3, 2.5, (n, 1))).astype(np.float32)  # |d| != 1: the second root
+    dev = sc.hit_batch(o, d)
+    orc = oracle.hit_batch(flat, o, d)
+    assert int((orc[:, 11] > 0.5).sum()) > n // 10
+    _check_hits(dev, orc, o, d, 1e-4)
+    with pytest.raises(lib.RtError) as ei:
+        sc.hit_batch(o, d, t_min=-1.0)
+    assert ei.value.code == abi.RT_ERR_UNSUPPORTED
+    sc.close()
+    twice = hittable_list([sphere([0, 0, 0], 2, GREY), sphere([0, 0, 0], 2, GREY)])
+    flat = flatten.flatten_world([constant_medium(twice, 0.5, [0.9, 0.9, 0.9])])
+    sc = gpu_ctx.scene(flat)
+    o = rng.uniform(-8, 8, (n, 3)).astype(np.float32)
+    tgt = rng.normal(size=(n, 3))
+    tgt = tgt / np.linalg.norm(tgt, axis=1, keepdims=True) * rng.uniform(0, 1.8, (n, 1))
+    # towards the boundary or (30 %) straight away from it, at many direction lengths
+    d = ((tgt - o) * rng.uniform(0.05, 1.5, (n, 1)) * rng.choice([-1.0, 1.0], (n, 1), p=[0.3, 0.7])).astype(np.float32)
+    xi = rng.random((n, 1)).astype(np.float32)
+    dev = sc.hit_batch(o, d, medium_xi=xi)
+    orc = oracle.hit_batch(flat, o, d, medium_xi=xi)
+    assert int((orc[:, 11] > 0.5).sum()) > n // 4
+    _check_hits(dev, orc, o, d, 1e-4)
+    sc.close()
