@@ -163,6 +163,25 @@ constexpr int waves_per_simd(uint32_t feat, bool count) {
   return count ? 4 : RT_WAVES_LEAN;
 }
 
+// Which instantiations draw the bounce's random-in-unit-sphere vectors with the whole wave
+// (wave_random_in_unit_sphere) instead of a rejection loop per lane. Measured: the all-features
+// kernels +1 to +3 % (it used to cost them registers they did not have), the sphere/BVH kernel
+// -8 % (random-scene) and -20 % (two-spheres).
+#ifndef RT_WAVE_DRAW_ALL
+#define RT_WAVE_DRAW_ALL 1
+#endif
+#ifndef RT_WAVE_DRAW_DEEP
+#define RT_WAVE_DRAW_DEEP 1
+#endif
+#ifndef RT_WAVE_DRAW_SPH
+#define RT_WAVE_DRAW_SPH 0
+#endif
+constexpr bool wave_draw(uint32_t feat) {
+  if (feat & F_SMALL) return true;
+  if (feat & F_NOISE) return (feat & F_DEEP) ? RT_WAVE_DRAW_DEEP != 0 : RT_WAVE_DRAW_ALL != 0;
+  return RT_WAVE_DRAW_SPH != 0;
+}
+
 // All arguments of k_render in one struct, so that its layout IS the kernarg segment's. Fields the
 // loop needs rarely (the camera's 21 doubles, the queue geometry) are not kept in SGPRs across the
 // traversal loops, where they would be spilled into VGPR lanes and read back with VALU
@@ -341,7 +360,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
 #ifdef RT_STAMPS
     ts3 = ts2; tsi = ts2;
 #endif
-    if constexpr ((FEAT & F_SMALL) != 0) {
+    if constexpr (wave_draw(FEAT)) {
       // core.clj:23: the closest hit, for the lanes that carry a path
       Rec rec;
       rec.mtype = -1;

@@ -190,7 +190,7 @@ def test_render_same_random_stream(gpu_ctx, oracle, name):
     sc.close()
 
 
-@pytest.mark.parametrize("name", ["cornell-box", "cornell-smoke", "two-spheres", "final-scene"])
+@pytest.mark.parametrize("name", ["cornell-box", "cornell-smoke", "two-spheres", "two-perlin-spheres", "earth", "final-scene"])
 def test_render_is_the_sum_of_its_samples_bit_for_bit(gpu_ctx, name):
     """The render loop (wave-wide sphere draw in the small-scene kernels, lanes refilled in place)
     against rt_sample_batch (one lane per sample, per-lane rejection loop): draws are addressed by
