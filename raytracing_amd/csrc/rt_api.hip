@@ -861,7 +861,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   if (chain_recs.size() > 1) features |= F_CHAINS;
   S.features = features;
 
-  brute_rects.resize(brute_rects.size() + RT_PAIR_STRIDE * RT_PAIR_BATCH, 0.f);  // slack for batched reads
+  brute_rects.resize(brute_rects.size() + RT_PAIR_STRIDE * RT_PAIR_SLACK, 0.f);  // slack for batched reads
   if ((rc = upload(sc, brute_rects, &S.brute_rects))) return rc;
   brute_boxes.resize(brute_boxes.size() + RT_BOX_STRIDE, 0.f);  // slack
   if ((rc = upload(sc, brute_boxes, &S.brute_boxes))) return rc;

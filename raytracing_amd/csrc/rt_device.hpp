@@ -586,25 +586,32 @@ RT_DEV void rect_pair(f2 k, f2 a0, f2 a1, f2 b0, f2 b1, int i0, int i1, const Ra
   }
 }
 
+// Pair records fetched per scalar-memory round trip. Fewer means more trips and fewer SGPRs held
+// across them; measured: 2 is best where rects are the world (+2 % on the Cornell boxes over 3, 4 is
+// 4 % slower), 1 where a group holds a light or two among spheres (+2.5 % on random-scene).
+template <class X>
+constexpr int pair_batch() { return (X::has(F_SMALL) || X::has(F_NOISE)) ? RT_PAIR_BATCH : 1; }
+
 // The rects of a brute-force group as pair records (DScene.brute_rects), XY pairs first, then XZ,
-// then YZ. RT_PAIR_BATCH records are fetched per trip with unconditional scalar loads (the table
+// then YZ. BATCH records are fetched per trip with unconditional scalar loads (the table
 // carries that much slack) and pinned in SGPRs before any of them is used, so a box costs one
 // scalar-memory round trip.
-template <class T>
+template <int BATCH, class T>
 RT_DEV void brute_rects(const float RT_CONST* R, int n_xy, int n_xz, int n_yz, const RayX& r, float tmin, Best& best,
                         T& tally) {
+  static_assert(BATCH >= 1 && BATCH <= RT_PAIR_SLACK, "the table carries RT_PAIR_SLACK records of slack");
   const int p_xy = (n_xy + 1) >> 1, p_xz = p_xy + ((n_xz + 1) >> 1), np = p_xz + ((n_yz + 1) >> 1);
-  for (int base = 0; base < np; base += RT_PAIR_BATCH) {
-    float v[RT_PAIR_BATCH * RT_PAIR_STRIDE];
+  for (int base = 0; base < np; base += BATCH) {
+    float v[BATCH * RT_PAIR_STRIDE];
 #pragma unroll
-    for (int q = 0; q < RT_PAIR_BATCH * RT_PAIR_STRIDE; ++q) v[q] = R[base * RT_PAIR_STRIDE + q];
-    asm volatile("" ::"s"(v[0]), "s"(v[1]), "s"(v[2]), "s"(v[3]), "s"(v[4]), "s"(v[5]), "s"(v[6]), "s"(v[7]), "s"(v[8]),
-                 "s"(v[9]), "s"(v[10]), "s"(v[11]), "s"(v[12]), "s"(v[13]), "s"(v[14]), "s"(v[15]), "s"(v[16]),
-                 "s"(v[17]), "s"(v[18]), "s"(v[19]), "s"(v[20]), "s"(v[21]), "s"(v[22]), "s"(v[23]), "s"(v[24]),
-                 "s"(v[25]), "s"(v[26]), "s"(v[27]), "s"(v[28]), "s"(v[29]), "s"(v[30]), "s"(v[31]), "s"(v[32]),
-                 "s"(v[33]), "s"(v[34]), "s"(v[35]));
+    for (int q = 0; q < BATCH * RT_PAIR_STRIDE; ++q) v[q] = R[base * RT_PAIR_STRIDE + q];
+    // (all of them pinned in SGPRs before the first use)
+    asm volatile("" ::"s"(v[0]), "s"(v[1]), "s"(v[2]), "s"(v[3]), "s"(v[4]), "s"(v[5]), "s"(v[6]), "s"(v[7]), "s"(v[8]), "s"(v[9]), "s"(v[10]), "s"(v[11]));
+    if constexpr (BATCH >= 2) asm volatile("" ::"s"(v[12]), "s"(v[13]), "s"(v[14]), "s"(v[15]), "s"(v[16]), "s"(v[17]), "s"(v[18]), "s"(v[19]), "s"(v[20]), "s"(v[21]), "s"(v[22]), "s"(v[23]));
+    if constexpr (BATCH >= 3) asm volatile("" ::"s"(v[24]), "s"(v[25]), "s"(v[26]), "s"(v[27]), "s"(v[28]), "s"(v[29]), "s"(v[30]), "s"(v[31]), "s"(v[32]), "s"(v[33]), "s"(v[34]), "s"(v[35]));
+    if constexpr (BATCH >= 4) asm volatile("" ::"s"(v[36]), "s"(v[37]), "s"(v[38]), "s"(v[39]), "s"(v[40]), "s"(v[41]), "s"(v[42]), "s"(v[43]), "s"(v[44]), "s"(v[45]), "s"(v[46]), "s"(v[47]));
 #pragma unroll
-    for (int j = 0; j < RT_PAIR_BATCH; ++j) {
+    for (int j = 0; j < BATCH; ++j) {
       const int q = base + j;
       if (q < np) {  // wave-uniform, as is the orientation of the pair
         const float* w = v + j * RT_PAIR_STRIDE;
@@ -692,7 +699,7 @@ RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best
     const DPrim RT_CONST* prims = cptr(S.prims);
     int first = G.first_prim;
     const int loose = G.loose;
-    brute_rects(cptr(S.brute_rects) + G.first_rect * RT_PAIR_STRIDE, loose & 255, (loose >> 8) & 255, (loose >> 16) & 255,
+    brute_rects<pair_batch<X>()>(cptr(S.brute_rects) + G.first_rect * RT_PAIR_STRIDE, loose & 255, (loose >> 8) & 255, (loose >> 16) & 255,
                 r, tmin, best, tally);
     brute_boxes(cptr(S.brute_boxes) + G.first_box * RT_BOX_STRIDE, loose >> 24, r, tmin, best, tally);
     first += G.n_xy + G.n_xz + G.n_yz;

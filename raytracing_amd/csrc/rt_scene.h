@@ -25,7 +25,10 @@
 #define RT_QUEUE_STRIDE 32      // dwords between two heads (each on a 128-byte line of its own)
 #define RT_PAIR_STRIDE 12      // dwords per pair record of DScene.brute_rects
 #define RT_BOX_STRIDE 12       // dwords per box record of DScene.brute_boxes
-#define RT_PAIR_BATCH 3        // pair records the brute-force loop fetches per scalar-memory round trip
+#ifndef RT_PAIR_BATCH
+#define RT_PAIR_BATCH 2        // pair records the rect kernels' brute-force loop fetches per scalar-memory round trip (1 to 4)
+#endif
+#define RT_PAIR_SLACK 4        // records of slack after the table: the most a batch reads past its end
 
 enum { DOP_TRANSLATE = 0, DOP_ROTATE_Y = 1 };
 
@@ -186,7 +189,7 @@ struct DScene {
                                  // then the two device primitive indices (int bits). Per group: XY pairs, XZ
                                  // pairs, YZ pairs. A run of odd length starts with a pair whose first slot
                                  // repeats its second (same index): the repeat is tested first and the real
-                                 // rect, accepting a tie, overwrites it. RT_PAIR_BATCH records of slack follow.
+                                 // rect, accepting a tie, overwrites it. RT_PAIR_SLACK records of slack follow.
   const float* brute_boxes;      // the closed boxes of the brute-force groups: x0 x1 y0 y1 z0 z1, then the device
                                  // primitive indices (int bits) of the faces z = z0, z = z1, y = y0, y = y1,
                                  // x = x0, x = x1. One record of slack follows.
