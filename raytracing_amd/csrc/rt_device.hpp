@@ -116,9 +116,10 @@ RT_DEV void philox(const Rng& g, uint32_t blk, uint32_t bounce, uint32_t purpose
     // one 32x32->64 multiply per word pair (v_mad_u64_u32)
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    // a ^ b ^ c in one instruction: gfx950's three-input bitwise op, truth table 0x96
+    c0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
     c1 = (uint32_t)p1;
-    c2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
     c3 = (uint32_t)p0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
