@@ -137,7 +137,9 @@ RT_DEV V3 cube_point(uint32_t wa, uint32_t wb) {
   // x, y: top 21 bits of each word; z: the 11 + 10 bits below them. (k - 2^20) * 2^-20 in [-1, 1)
   const float S = 9.5367431640625e-7f;  // 2^-20
   uint32_t xi = wa >> 11, yi = wb >> 11, zi = ((wa & 0x7FFu) << 10) | ((wb >> 1) & 0x3FFu);
-  return mk((float)((int)xi - (1 << 20)) * S, (float)((int)yi - (1 << 20)) * S, (float)((int)zi - (1 << 20)) * S);
+  // k * 2^-20 - 1 as one FMA on the converted field: k < 2^21 converts exactly and the result,
+  // (k - 2^20) / 2^20, is representable, so this is the same value as subtracting first
+  return mk(fmaf((float)xi, S, -1.0f), fmaf((float)yi, S, -1.0f), fmaf((float)zi, S, -1.0f));
 }
 template <class T>
 RT_DEV V3 random_in_unit_sphere(const Rng& g, uint32_t bounce, T& tally) {
