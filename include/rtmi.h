@@ -199,6 +199,18 @@ int rt_abi_version(void);
 /* Uploads a world and builds its device form (flattened instance chains, GPU-built BVHs).
  * Stands in for holding the `world` vector that core.clj:66-88 selects. */
 int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out);
+/* The same with a choice of tree builder for the large groups (the reference builds its own
+ * BvhNode trees at base.clj:137-164; the closest hit does not depend on the tree's shape, so the
+ * library builds its own over the flattened leaves). Records and frames are identical, bit for
+ * bit, whichever builder ran; only the speed of the traversal differs. */
+enum {
+  RT_BVH_DEFAULT = 0,   /* what rt_scene_create uses                                          */
+  RT_BVH_DEVICE = 1,    /* built on the GPU: Morton order, radix tree, bottom-up fit, then
+                           surface-area refinement of the tree, all in kernels                */
+  RT_BVH_HOST_SAH = 2   /* exact surface-area sweep on the host (up to 32768 primitives per
+                           group; larger groups fall back to the GPU builder)                 */
+};
+int rt_scene_create_with(rt_ctx* ctx, const rt_scene_desc* desc, int32_t bvh_builder, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
 /* The sample loop of core.clj:96-127 over this call's shard of tiles and slice of samples.
@@ -233,6 +245,37 @@ int rt_tonemap_device(rt_ctx* ctx, const float* d_rgb_sum, int32_t n_pixels, int
 int rt_hit_batch(rt_ctx* ctx, const rt_scene* scene, int32_t n, const float* orig3,
                  const float* dir3, const float* time, float t_min, float t_max,
                  const float* medium_xi, rt_hit* out);
+
+/* The kernels are compiled once per feature set ("instantiation": 0 rects under chains,
+ * 1 + constant media, 2 spheres / BVH / metal / dielectric / checker, 3 everything the reference's
+ * worlds use, 4 the same for worlds with BVHs, 5 + media with arbitrary boundaries) and a world
+ * renders on the smallest one that covers it. rt_scene_get_variants reports which one that is and
+ * the bit mask of all that cover the world; rt_hit_batch_variant answers rt_hit_batch's question
+ * with a chosen instantiation (RT_VARIANT_RENDER = the one the render uses, RT_VARIANT_GENERAL =
+ * instantiation 5, which is what rt_hit_batch runs), so a test can show that every instantiation
+ * returns the same records. An instantiation that does not cover the world is refused
+ * (RT_ERR_UNSUPPORTED). */
+#define RT_N_VARIANTS 6
+#define RT_VARIANT_GENERAL (-1)
+#define RT_VARIANT_RENDER (-2)
+int rt_scene_get_variants(const rt_scene* scene, int32_t* render_variant, uint32_t* covering_mask);
+int rt_hit_batch_variant(rt_ctx* ctx, const rt_scene* scene, int32_t variant, int32_t n, const float* orig3,
+                         const float* dir3, const float* time, float t_min, float t_max,
+                         const float* medium_xi, rt_hit* out);
+
+/* Parity hook for (scatter mat r rec) / (emitted mat u v p), materials.clj:10-96: one ray-color
+ * invocation (core.clj:23-25) per ray with t-min 0.001, t-max inf and the keyed random draws of
+ * pixel px[i], sample smp[i], bounce bounce[i] (seed = params' seed). Runs on the instantiation
+ * the render uses. hit = 0: the ray left the world (other fields 0). ok = 1: `orig dir time` are
+ * the scattered ray and `attenuation` its colour; ok = 0: `emitted` is the material's emission. */
+typedef struct rt_scatter {
+  int32_t hit, ok, mat_id, pad;
+  float orig[3], dir[3], time;
+  float attenuation[3], emitted[3];
+} rt_scatter;
+int rt_scatter_batch(rt_ctx* ctx, const rt_scene* scene, uint64_t seed, int32_t n, const float* orig3,
+                     const float* dir3, const float* time, const int32_t* px, const int32_t* smp,
+                     const int32_t* bounce, rt_scatter* out);
 
 /* Parity hook for the scatter/texture functions: per-sample radiance of single samples,
  * host buffers. For i in [0,n): pixel index px[i], global sample index smp[i] ->

@@ -17,6 +17,9 @@ RT_MAT_DSTRIDE = 4
 RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_NOISE, RT_TEX_IMAGE = range(4)
 RT_TEX_DSTRIDE, RT_TEX_ISTRIDE = 4, 2
 RT_FLAG_COUNTERS = 1
+RT_BVH_DEFAULT, RT_BVH_DEVICE, RT_BVH_HOST_SAH = 0, 1, 2
+RT_N_VARIANTS, RT_VARIANT_GENERAL, RT_VARIANT_RENDER = 6, -1, -2
+VARIANT_NAMES = ["V_RECT", "V_SMOKE", "V_SPH", "V_ALL", "V_ALL_DEEP", "V_FULL"]
 
 RT_EVENT_NAMES = [
     "aabb_test", "sphere_test", "sphere_root", "sphere_record", "msphere_center", "rect_test",
@@ -68,6 +71,12 @@ class rt_hit(C.Structure):
     _fields_ = [("t", C.c_float), ("p", C.c_float * 3), ("normal", C.c_float * 3),
                 ("u", C.c_float), ("v", C.c_float),
                 ("front_face", C.c_int32), ("mat_id", C.c_int32), ("hit", C.c_int32)]
+
+
+class rt_scatter(C.Structure):
+    _fields_ = [("hit", C.c_int32), ("ok", C.c_int32), ("mat_id", C.c_int32), ("pad", C.c_int32),
+                ("orig", C.c_float * 3), ("dir", C.c_float * 3), ("time", C.c_float),
+                ("attenuation", C.c_float * 3), ("emitted", C.c_float * 3)]
 
 
 class rt_scene_info(C.Structure):

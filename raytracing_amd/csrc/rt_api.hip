@@ -39,6 +39,20 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// Runs f(); a C++ exception never leaves the library.
+template <class F>
+int guarded(const char* what, F&& f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return fail(RT_ERR_OOM, "out of host memory in %s", what);
+  } catch (const std::exception& e) {
+    return fail(RT_ERR_ARG, "%s: %s", what, e.what());
+  } catch (...) {
+    return fail(RT_ERR_ARG, "%s: unknown failure", what);
+  }
+}
+
 #define HIPCHK(expr)                                                                         \
   do {                                                                                       \
     hipError_t e_ = (expr);                                                                  \
@@ -51,6 +65,8 @@ int fail(int code, const char* fmt, ...) {
 struct rt_ctx {
   int device = 0;
   int n_cu = 0;
+  int clock_khz = 0;
+  size_t lds_max = 65536;  // LDS a workgroup may ask for on this device
   // reusable device workspace
   uint32_t* d_queue = nullptr;              // the heads of the work-item queue (RT_QUEUE_HEADS lines)
   unsigned long long* d_stats = nullptr;    // 2 + RT_EV_COUNT words
@@ -116,7 +132,8 @@ int validate_desc(const rt_scene_desc* d) {
     int t = d->mat_type[i];
     if (t < RT_MAT_LAMBERTIAN || t > RT_MAT_ISOTROPIC) return fail(RT_ERR_ARG, "material %d: unknown type %d", i, t);
     bool textured = t == RT_MAT_LAMBERTIAN || t == RT_MAT_DIFFUSE_LIGHT || t == RT_MAT_ISOTROPIC;
-    if (textured && (d->mat_tex[i] < 0 || d->mat_tex[i] >= d->n_tex))
+    // metal and dielectric carry no texture: -1, or any valid index (it is never read)
+    if (d->mat_tex[i] >= d->n_tex || d->mat_tex[i] < (textured ? 0 : -1))
       return fail(RT_ERR_ARG, "material %d: texture out of range", i);
   }
   for (int i = 0; i < d->n_tex; ++i) {
@@ -363,6 +380,21 @@ int fill_render(const rt_scene* sc, const rt_camera* cam, const rt_params* p, DR
   return RT_OK;
 }
 
+int init_ctx(rt_ctx* ctx) {
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+  ctx->n_cu = prop.multiProcessorCount;
+  ctx->clock_khz = prop.clockRate;
+  int lds_max = 0;
+  HIPCHK(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device));
+  ctx->lds_max = (size_t)lds_max;
+  HIPCHK(hipMalloc(&ctx->d_queue, RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4));
+  HIPCHK(hipMalloc(&ctx->d_stats, sizeof(unsigned long long) * (2 + RT_EV_COUNT)));
+  HIPCHK(hipEventCreate(&ctx->ev0));
+  HIPCHK(hipEventCreate(&ctx->ev1));
+  return RT_OK;
+}
+
 }  // namespace
 
 // ========================================================================== the C ABI
@@ -384,13 +416,11 @@ int rt_init(int32_t device_id, rt_ctx** out) {
   rt_ctx* ctx = new (std::nothrow) rt_ctx();
   if (!ctx) return fail(RT_ERR_OOM, "out of host memory");
   ctx->device = device_id;
-  hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, device_id));
-  ctx->n_cu = prop.multiProcessorCount;
-  HIPCHK(hipMalloc(&ctx->d_queue, RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4));
-  HIPCHK(hipMalloc(&ctx->d_stats, sizeof(unsigned long long) * (2 + RT_EV_COUNT)));
-  HIPCHK(hipEventCreate(&ctx->ev0));
-  HIPCHK(hipEventCreate(&ctx->ev1));
+  const int rc = init_ctx(ctx);
+  if (rc) {  // whatever was allocated so far goes back; the message of the failing call stays
+    rt_shutdown(ctx);
+    return rc;
+  }
   *out = ctx;
   return RT_OK;
 }
@@ -414,9 +444,11 @@ void rt_scene_destroy(rt_scene* sc) {
   delete sc;
 }
 
-int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
+// May throw (std::vector, std::map, std::function allocate): only called through guarded().
+static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builder, rt_scene** out) {
   if (!ctx || !out) return fail(RT_ERR_ARG, "ctx or out is NULL");
   *out = nullptr;
+  if (bvh_builder < RT_BVH_DEFAULT || bvh_builder > RT_BVH_HOST_SAH) return fail(RT_ERR_ARG, "unknown BVH builder %d", bvh_builder);
   int rc = validate_desc(d);
   if (rc) return rc;
   HIPCHK(hipSetDevice(ctx->device));
@@ -821,7 +853,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   S.prims = d_prims;
 
   // BVHs for the large groups: surface-area trees from the host up to RT_SAH_MAX primitives, the
-  // device's Morton build beyond (or when RTMI_BVH_MORTON is set, to compare the two)
+  // device's Morton build beyond (or when the caller asks for it)
   int n_bvh_nodes = 0;
   auto group_size = [](const DGroup& G) { return G.n_xy + G.n_xz + G.n_yz + G.n_sph; };
   for (auto& G : groups)
@@ -839,7 +871,8 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
     const int n_prims = group_size(G);
     if (n_prims <= RT_BRUTE_MAX) continue;
     int height = 0;
-    hipError_t e = (n_prims <= RT_SAH_MAX && !std::getenv("RTMI_BVH_MORTON"))
+    const bool host_sah = bvh_builder != RT_BVH_DEVICE && n_prims <= RT_SAH_MAX;
+    hipError_t e = host_sah
                        ? build_bvh_sah(prims.data(), G.first_prim, n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0)
                        : build_bvh(d_prims, G.first_prim, n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e));
@@ -883,9 +916,15 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   S.n_media = d->n_media;
   S.n_perlin = d->n_perlin;
 
+  // the largest instantiation's need bounds every kernel this scene may run on (hit and scatter hooks included)
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
-  if (lds > 64 * 1024)
-    return fail(RT_ERR_UNSUPPORTED, "scene needs %zu bytes of LDS per workgroup (BVH height %d); limit is 65536", lds, max_height);
+  size_t lds_any = lds;
+  for (int v = 0; v < RT_N_VARIANTS; ++v)
+    if (variant_covers(S, v)) lds_any = std::max(lds_any, variant_lds_bytes(S, RT_BLOCK, v));
+  if (lds_any > ctx->lds_max)
+    return fail(RT_ERR_UNSUPPORTED, "scene needs %zu bytes of LDS per workgroup (BVH height %d); this device allows %zu",
+                lds_any, max_height, ctx->lds_max);
+  HIPCHK(allow_lds(lds_any));
   HIPCHK(render_occupancy(S, false, &sc->blocks_per_cu[0]));
   HIPCHK(render_occupancy(S, true, &sc->blocks_per_cu[1]));
   if (sc->blocks_per_cu[0] < 1 || sc->blocks_per_cu[1] < 1) return fail(RT_ERR_HIP, "path kernel does not fit a compute unit");
@@ -901,14 +940,33 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   return RT_OK;
 }
 
+int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
+  return guarded("rt_scene_create", [&] { return scene_create_impl(ctx, d, RT_BVH_DEFAULT, out); });
+}
+int rt_scene_create_with(rt_ctx* ctx, const rt_scene_desc* d, int32_t bvh_builder, rt_scene** out) {
+  return guarded("rt_scene_create_with", [&] { return scene_create_impl(ctx, d, bvh_builder, out); });
+}
+
+int rt_scene_get_variants(const rt_scene* sc, int32_t* render_var, uint32_t* covering_mask) {
+  if (!sc) return fail(RT_ERR_ARG, "scene is NULL");
+  if (render_var) *render_var = render_variant(sc->S);
+  if (covering_mask) {
+    uint32_t m = 0;
+    for (int v = 0; v < RT_N_VARIANTS; ++v)
+      if (variant_covers(sc->S, v)) m |= 1u << v;
+    *covering_mask = m;
+  }
+  return RT_OK;
+}
+
 int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
   if (!sc || !out) return fail(RT_ERR_ARG, "scene or out is NULL");
   *out = sc->info;
   return RT_OK;
 }
 
-int rt_render_device(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, float* d_rgb_sum,
-                     uint32_t* d_argb, rt_stats* stats, void* hip_stream) {
+static int render_device_impl(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, float* d_rgb_sum,
+                              uint32_t* d_argb, rt_stats* stats, void* hip_stream) {
   if (!ctx || !sc || sc->ctx != ctx) return fail(RT_ERR_ARG, "ctx/scene is NULL or the scene belongs to another context");
   DRender R;
   int rc = fill_render(sc, cam, p, R);
@@ -953,6 +1011,11 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, cons
   return RT_OK;
 }
 
+int rt_render_device(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, float* d_rgb_sum,
+                     uint32_t* d_argb, rt_stats* stats, void* hip_stream) {
+  return guarded("rt_render_device", [&] { return render_device_impl(ctx, sc, cam, p, d_rgb_sum, d_argb, stats, hip_stream); });
+}
+
 int rt_render(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, float* rgb_sum,
               uint32_t* argb, rt_stats* stats) {
   if (!ctx || !p) return fail(RT_ERR_ARG, "ctx or params is NULL");
@@ -981,10 +1044,16 @@ int rt_tonemap_device(rt_ctx* ctx, const float* d_rgb_sum, int32_t n_pixels, int
   return RT_OK;
 }
 
-int rt_hit_batch(rt_ctx* ctx, const rt_scene* sc, int32_t n, const float* orig3, const float* dir3, const float* time,
-                 float t_min, float t_max, const float* medium_xi, rt_hit* out) {
+int rt_hit_batch_variant(rt_ctx* ctx, const rt_scene* sc, int32_t variant, int32_t n, const float* orig3,
+                         const float* dir3, const float* time, float t_min, float t_max, const float* medium_xi,
+                         rt_hit* out) {
   if (!ctx || !sc || sc->ctx != ctx) return fail(RT_ERR_ARG, "ctx/scene is NULL or the scene belongs to another context");
   if (n < 0 || (n > 0 && (!orig3 || !dir3 || !out))) return fail(RT_ERR_ARG, "bad ray batch arguments");
+  if (variant == RT_VARIANT_GENERAL) variant = RT_N_VARIANTS - 1;
+  if (variant == RT_VARIANT_RENDER) variant = render_variant(sc->S);
+  if (variant < 0 || variant >= RT_N_VARIANTS) return fail(RT_ERR_ARG, "unknown kernel instantiation %d", variant);
+  if (!variant_covers(sc->S, variant))
+    return fail(RT_ERR_UNSUPPORTED, "kernel instantiation %d does not cover this world (features 0x%x)", variant, sc->S.features);
   if (n == 0) return RT_OK;
   if (t_min < 0.f && sc->n_shadowed_spheres > 0)
     return fail(RT_ERR_UNSUPPORTED, "t_min < 0 with %d coincident duplicate sphere(s) in the world: they are left out of the "
@@ -1013,13 +1082,55 @@ int rt_hit_batch(rt_ctx* ctx, const rt_scene* sc, int32_t n, const float* orig3,
   HIPCHK(hipMemcpy(d_d, dir3, b3, hipMemcpyHostToDevice));
   if (time) HIPCHK(hipMemcpy(d_t, time, b1, hipMemcpyHostToDevice));
   if (medium_xi && sc->n_media > 0) HIPCHK(hipMemcpy(d_xi, medium_xi, (size_t)n * sc->n_media * sizeof(float), hipMemcpyHostToDevice));
-  HIPCHK(launch_hit_batch(sc->S, n, d_o, d_d, time ? d_t : nullptr, t_min, t_max, medium_xi ? d_xi : nullptr, d_out, 0));
+  HIPCHK(launch_hit_batch(sc->S, variant, n, d_o, d_d, time ? d_t : nullptr, t_min, t_max, medium_xi ? d_xi : nullptr, d_out, 0));
   HIPCHK(hipMemcpy(out, d_out, bout, hipMemcpyDeviceToHost));
   return RT_OK;
 }
 
-int rt_sample_batch(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, int32_t n,
-                    const int32_t* px, const int32_t* smp, float* out_rgb) {
+int rt_hit_batch(rt_ctx* ctx, const rt_scene* sc, int32_t n, const float* orig3, const float* dir3, const float* time,
+                 float t_min, float t_max, const float* medium_xi, rt_hit* out) {
+  return rt_hit_batch_variant(ctx, sc, RT_VARIANT_GENERAL, n, orig3, dir3, time, t_min, t_max, medium_xi, out);
+}
+
+int rt_scatter_batch(rt_ctx* ctx, const rt_scene* sc, uint64_t seed, int32_t n, const float* orig3, const float* dir3,
+                     const float* time, const int32_t* px, const int32_t* smp, const int32_t* bounce, rt_scatter* out) {
+  if (!ctx || !sc || sc->ctx != ctx) return fail(RT_ERR_ARG, "ctx/scene is NULL or the scene belongs to another context");
+  if (n < 0 || (n > 0 && (!orig3 || !dir3 || !px || !smp || !bounce || !out))) return fail(RT_ERR_ARG, "bad scatter batch arguments");
+  if (n == 0) return RT_OK;
+  for (int i = 0; i < n; ++i) {
+    if (px[i] < 0 || smp[i] < 0 || bounce[i] < 0 || bounce[i] >= (1 << 26))
+      return fail(RT_ERR_ARG, "ray %d: pixel, sample or bounce index out of range", i);
+    const float t = time ? time[i] : 0.f;
+    if (sc->has_time_bounds && !(t >= sc->time_lo && t <= sc->time_hi))
+      return fail(RT_ERR_ARG, "ray %d: time %g outside [%g, %g]", i, t, sc->time_lo, sc->time_hi);
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t b3 = (size_t)n * 3 * sizeof(float), b1 = (size_t)n * sizeof(float), bout = (size_t)n * sizeof(rt_scatter);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  int rc = ensure_io(ctx, al(b3) * 2 + al(b1) * 4 + al(bout));
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->d_io);
+  float* d_o = reinterpret_cast<float*>(base);
+  float* d_d = reinterpret_cast<float*>(base + al(b3));
+  float* d_t = reinterpret_cast<float*>(base + al(b3) * 2);
+  int* d_px = reinterpret_cast<int*>(base + al(b3) * 2 + al(b1));
+  int* d_smp = reinterpret_cast<int*>(base + al(b3) * 2 + al(b1) * 2);
+  int* d_b = reinterpret_cast<int*>(base + al(b3) * 2 + al(b1) * 3);
+  rt_scatter* d_out = reinterpret_cast<rt_scatter*>(base + al(b3) * 2 + al(b1) * 4);
+  HIPCHK(hipMemcpy(d_o, orig3, b3, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_d, dir3, b3, hipMemcpyHostToDevice));
+  if (time) HIPCHK(hipMemcpy(d_t, time, b1, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_px, px, b1, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_smp, smp, b1, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_b, bounce, b1, hipMemcpyHostToDevice));
+  HIPCHK(launch_scatter_batch(sc->S, (uint32_t)seed, (uint32_t)(seed >> 32), n, d_o, d_d, time ? d_t : nullptr, d_px, d_smp,
+                              d_b, d_out, 0));
+  HIPCHK(hipMemcpy(out, d_out, bout, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+static int sample_batch_impl(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, int32_t n,
+                             const int32_t* px, const int32_t* smp, float* out_rgb) {
   if (!ctx || !sc || sc->ctx != ctx) return fail(RT_ERR_ARG, "ctx/scene is NULL or the scene belongs to another context");
   DRender R;
   int rc = fill_render(sc, cam, p, R);
@@ -1044,6 +1155,11 @@ int rt_sample_batch(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const
   HIPCHK(launch_sample_batch(sc->S, C, R, n, d_px, d_smp, d_out, 0));
   HIPCHK(hipMemcpy(out_rgb, d_out, bo, hipMemcpyDeviceToHost));
   return RT_OK;
+}
+
+int rt_sample_batch(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, int32_t n,
+                    const int32_t* px, const int32_t* smp, float* out_rgb) {
+  return guarded("rt_sample_batch", [&] { return sample_batch_impl(ctx, sc, cam, p, n, px, smp, out_rgb); });
 }
 
 // ------------------------------------------------------------------------------- scene files
@@ -1135,12 +1251,18 @@ int desc_from_blob(const unsigned char* b, uint64_t n, rt_scene_desc* d, std::ve
 
 }  // namespace
 
-uint64_t rt_scene_file_size(const rt_scene_desc* d) {
+static uint64_t scene_file_size_impl(const rt_scene_desc* d) {
   if (validate_desc(d) != RT_OK) return 0;
   int32_t c[9];
   desc_counts(d, c);
   uint64_t total = scene_spans(c).images;
   for (int i = 0; i < d->n_images; ++i) total += pad8((uint64_t)d->img_w[i] * (uint64_t)d->img_h[i] * 3u);
+  return total;
+}
+
+uint64_t rt_scene_file_size(const rt_scene_desc* d) {
+  uint64_t total = 0;
+  if (guarded("rt_scene_file_size", [&] { total = scene_file_size_impl(d); return RT_OK; }) != RT_OK) return 0;
   return total;
 }
 

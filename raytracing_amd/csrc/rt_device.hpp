@@ -383,7 +383,7 @@ RT_DEV bool wins_tie(int cand_type, int cand_idx, int best_type, int best_idx) {
 
 // One primitive visited OUT of scan order (BVH leaves): explicit tie rule on the ranks.
 template <class X, class T>
-RT_DEV void test_prim_any_order(const DScene& S, int idx, const RayX& r, float tmin, Best& best, T& tally) {
+RT_DEV void test_prim_any_order(const DScene& S, int idx, const RayX& r, float tmin, Best& best, T& tally, double tmin64) {
   const DPrim RT_CONST* prims = cptr(S.prims);
   const DPrim RT_CONST& P = prims[idx];
   const int type = prim_type(P.type);
@@ -408,7 +408,7 @@ RT_DEV void test_prim_any_order(const DScene& S, int idx, const RayX& r, float t
     }
   } else {
     if constexpr (X::has(F_SPHERES)) {
-      if (!sphere_t<sphere_mode<X>()>(P, type, r, (double)tmin, __builtin_inff(), t, root, tally)) return;
+      if (!sphere_t<sphere_mode<X>()>(P, type, r, tmin64, __builtin_inff(), t, root, tally)) return;
       if (t > best.t) return;
       if (t == best.t) {
         if (best.prim < 0) return;  // t == t_max with nothing hit yet: the strict test fails
@@ -482,7 +482,7 @@ RT_DEV bool slab16(_Float16 mnx, _Float16 mny, _Float16 mnz, _Float16 mxx, _Floa
 // reference's tie rule explicitly.
 #define RT_BVH_DONE 0x7fffffff
 template <class X, class T>
-RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best& best, T& tally) {
+RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best& best, T& tally, double tmin64) {
   const DScene& S = ctx.S;
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   const u4 RT_CONST* nodes4 = reinterpret_cast<const u4 RT_CONST*>(cptr(S.nodes));
@@ -537,7 +537,7 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
     __builtin_amdgcn_sched_barrier(0); st_b = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #endif
     if (node != RT_BVH_DONE) {  // a leaf
-      test_prim_any_order<X>(S, ~node, r, tmin, best, tally);
+      test_prim_any_order<X>(S, ~node, r, tmin, best, tally, tmin64);
       if (sp > 0) {
         sp -= stride;
         node = ctx.lds_stack[sp];
@@ -690,14 +690,16 @@ RT_DEV void brute_boxes(const float RT_CONST* B, int n_box, const RayX& r, float
 }
 
 // Closest hit of group g for the world ray wr with t in (tmin, best.t].
+// tmin64: the lower bound the spheres compare their FP64 roots with (the FP32 bound widened, unless
+// the caller holds a more exact one).
 template <class X, class T>
-RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best, T& tally) {
+RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best, T& tally, double tmin64) {
   const DScene& S = ctx.S;
   const DGroup RT_CONST& G = cptr(S.groups)[g];
   const RayX r = group_ray<X>(S, g, G.flags, G.rc, G.rs, G.bx, G.by, G.bz, wr, tally);
   const int bvh_root = G.bvh_root;
   if (X::has(F_BVH) && bvh_root >= 0) {
-    if constexpr (X::has(F_BVH)) bvh_traverse(ctx, bvh_root, r, tmin, best, tally);
+    if constexpr (X::has(F_BVH)) bvh_traverse(ctx, bvh_root, r, tmin, best, tally, tmin64);
   } else {
     const DPrim RT_CONST* prims = cptr(S.prims);
     int first = G.first_prim;
@@ -712,7 +714,7 @@ RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best
         const DPrim RT_CONST& P = prims[first + i];
         float t = 0.f;
         double root = 0.0;
-        bool ok = sphere_t<sphere_mode<X>()>(P, prim_type(P.type), r, (double)tmin, best.t, t, root, tally);
+        bool ok = sphere_t<sphere_mode<X>()>(P, prim_type(P.type), r, tmin64, best.t, t, root, tally);
         best.t = ok ? t : best.t;
         best.prim = ok ? first + i : best.prim;
         best.root = ok ? root : best.root;
@@ -857,6 +859,13 @@ RT_DEV void chain_unwind(const X& ctx, int chain, V3 world_d, Rec& rec, T& tally
 }
 
 // -------------------------------------------------------------------------------- media
+// t + 0.0001 (constant_medium.clj:13) for an FP32 t: where the sum is absorbed (|t| >= 2048) the next
+// float above t, so that the first boundary hit itself stays excluded as it is in FP64.
+RT_DEV float after_t(float t) {
+  const float s = t + 0.0001f;
+  const float up = __int_as_float(__float_as_int(t) + (t > 0.0f ? 1 : -1));
+  return s > t ? s : up;
+}
 // constant_medium.clj:11-38 for medium m; xi is the uniform of line 32 (scripted when have_xi,
 // else word m & 3 of `block`, the keyed stream's block m >> 2 for this bounce). True with the hit parameter when the free-flight distance
 // ends inside the boundary, t in [t1, t2] within (tmin, tmax]. The boundary groups carry their
@@ -883,10 +892,14 @@ RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax,
       double root1, root2;
       if (!sphere_roots<sphere_mode<X>()>(P, prim_type(P.type), r, root1, root2, tally)) return false;
       const double NINF = -(double)INF;
-      if (root1 > NINF && (float)root1 < INF) b1.t = (float)root1;
-      else if (root2 > NINF && (float)root2 < INF) b1.t = (float)root2;
+      double first;
+      if (root1 > NINF && (float)root1 < INF) first = root1;
+      else if (root2 > NINF && (float)root2 < INF) first = root2;
       else return false;
-      const double tmin2 = (double)(b1.t + 0.0001f);
+      b1.t = (float)first;
+      // constant_medium.clj:13 adds 0.0001 to the FP64 root: in FP32 the sum is absorbed from
+      // |t| = 2048 on and the entry root would be accepted again as the exit
+      const double tmin2 = first + 0.0001;
       if (root1 > tmin2 && (float)root1 < INF) b2.t = (float)root1;
       else if (root2 > tmin2 && (float)root2 < INF) b2.t = (float)root2;
       else return false;
@@ -908,7 +921,7 @@ RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax,
       tally.template add<RT_EV_RECT_TEST>(12);
       const BoxSlab s = box_slab(w, r);
       if (!box_accept(s, -INF, INF, b1.t)) return false;
-      if (!box_accept(s, b1.t + 0.0001f, INF, b2.t)) return false;
+      if (!box_accept(s, after_t(b1.t), INF, b2.t)) return false;
       b1.prim = b2.prim = G.first_prim;
     }
   }
@@ -916,9 +929,11 @@ RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax,
     // any other boundary: two closest-hit queries over its groups. Only the instantiations for
     // worlds that have such a medium carry these loops (the host sets F_MEDIA_ANY).
     if constexpr (X::has(F_MEDIA_ANY)) {
-      for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, -INF, b1, tally);
+      for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, -INF, b1, tally, -(double)INF);
       if (b1.prim < 0) return false;
-      for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, b1.t + 0.0001f, b2, tally);
+      // (spheres compare against the winner's FP64 root + 0.0001 when a sphere won)
+      const double tmin2 = b1.prim >= 0 && !is_rect(prim_type(cptr(S.prims)[b1.prim].type)) ? b1.root + 0.0001 : (double)after_t(b1.t);
+      for (int gi = 0; gi < n_groups; ++gi) group_hit(ctx, first_group + gi, wr, after_t(b1.t), b2, tally, tmin2);
       if (b2.prim < 0) return false;
     } else {
       return false;  // a medium the root never reaches (no boundary groups)
@@ -952,7 +967,7 @@ RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, con
   const DScene& S = ctx.S;
   Best best{tmax, -1, 0.0};
   const int n_surface = S.n_surface_groups;
-  for (int gi = 0; gi < n_surface; ++gi) group_hit(ctx, gi, wr, tmin, best, tally);
+  for (int gi = 0; gi < n_surface; ++gi) group_hit(ctx, gi, wr, tmin, best, tally, (double)tmin);
 #ifdef RT_STAMPS
   if (g_stamp_inner) { __builtin_amdgcn_sched_barrier(0); *g_stamp_inner = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #endif

@@ -480,12 +480,15 @@ __global__ void k_tonemap(const float* __restrict__ rgb_sum, int n_pixels, int s
   argb[pix] = pack_pixel(rgb_sum[3 * (size_t)pix], rgb_sum[3 * (size_t)pix + 1], rgb_sum[3 * (size_t)pix + 2], spp);
 }
 
+// FEAT: any instantiation whose mask covers the scene answers with the same records, bit for bit
+// (tests/test_gpu_variants.py); the render kernels share every device function with this one.
+template <uint32_t FEAT>
 __global__ __launch_bounds__(RT_BLOCK) void k_hit_batch(DScene S, int n, const float* __restrict__ orig3,
                                                         const float* __restrict__ dir3,
                                                         const float* __restrict__ time, float tmin, float tmax,
                                                         const float* __restrict__ medium_xi, rt_hit* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char lds[];
-  Ctx<F_ALL | F_MEDIA_ANY> X = make_ctx<F_ALL | F_MEDIA_ANY>(S, lds);
+  Ctx<FEAT> X = make_ctx<FEAT>(S, lds);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Ray r{mk(orig3[3 * i], orig3[3 * i + 1], orig3[3 * i + 2]), mk(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]),
@@ -507,6 +510,46 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hit_batch(DScene S, int n, const f
     h.hit = 1;
   }
   out[i] = h;
+}
+
+// One ray-color invocation (core.clj:23-25) for caller-supplied rays: the closest hit, then
+// (scatter mat r rec) and (emitted mat u v p) of the material hit, with the keyed draws of
+// (pixel px, sample smp, bounce) — what the render loop does for that path at that bounce.
+template <uint32_t FEAT>
+__global__ __launch_bounds__(RT_BLOCK) void k_scatter_batch(DScene S, uint32_t seed_lo, uint32_t seed_hi, int n,
+                                                            const float* __restrict__ orig3, const float* __restrict__ dir3,
+                                                            const float* __restrict__ time, const int* __restrict__ px,
+                                                            const int* __restrict__ smp, const int* __restrict__ bounce,
+                                                            rt_scatter* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  Ctx<FEAT> X = make_ctx<FEAT>(S, lds);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Ray r{mk(orig3[3 * i], orig3[3 * i + 1], orig3[3 * i + 2]), mk(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]),
+        time ? time[i] : 0.f};
+  Rng g{(uint32_t)px[i], (uint32_t)smp[i], seed_lo, seed_hi};
+  const uint32_t b = (uint32_t)bounce[i];
+  Tally<false> tally;
+  Rec rec;
+  rt_scatter s;
+  s.hit = 0; s.ok = 0; s.mat_id = -1; s.pad = 0;
+  s.orig[0] = s.orig[1] = s.orig[2] = 0.f; s.dir[0] = s.dir[1] = s.dir[2] = 0.f; s.time = 0.f;
+  s.attenuation[0] = s.attenuation[1] = s.attenuation[2] = 0.f;
+  s.emitted[0] = s.emitted[1] = s.emitted[2] = 0.f;
+  if (closest_hit(X, r, 0.001f, __builtin_inff(), g, b, nullptr, false, false, rec, tally)) {
+    V3 att, em;
+    const bool ok = scatter<false>(X, rec, r, g, b, mk(0.f, 0.f, 0.f), att, em, tally);
+    s.hit = 1; s.ok = ok ? 1 : 0; s.mat_id = rec.mat;
+    if (ok) {
+      s.orig[0] = r.o.x; s.orig[1] = r.o.y; s.orig[2] = r.o.z;
+      s.dir[0] = r.d.x; s.dir[1] = r.d.y; s.dir[2] = r.d.z;
+      s.time = r.tm;
+      s.attenuation[0] = att.x; s.attenuation[1] = att.y; s.attenuation[2] = att.z;
+    } else {
+      s.emitted[0] = em.x; s.emitted[1] = em.y; s.emitted[2] = em.z;
+    }
+  }
+  out[i] = s;
 }
 
 template <uint32_t FEAT>
@@ -555,12 +598,14 @@ int pick_variant(const DScene& S) {
   return (S.features & F_BVH) ? 4 : 3;
 }
 
-size_t shade_lds_bytes(const DScene& S, int block) {
+// LDS per workgroup of instantiation `variant` (the F_SMALL ones, 0 and 1, keep the record tables there).
+size_t variant_lds_bytes(const DScene& S, int block, int variant) {
   size_t vec_bytes = (size_t)S.n_perlin * 4096;
   size_t perm_bytes = ((size_t)S.n_perlin * 768 + 15) & ~(size_t)15;
-  size_t info_bytes = pick_variant(S) < 2 ? (size_t)S.n_prims * sizeof(DPrimInfo) + (size_t)S.n_chains * sizeof(DChainRec) : 0;
+  size_t info_bytes = variant < 2 ? (size_t)S.n_prims * sizeof(DPrimInfo) + (size_t)S.n_chains * sizeof(DChainRec) : 0;
   return vec_bytes + perm_bytes + info_bytes + (size_t)(block / 64) * 1024 + (size_t)block * (size_t)S.bvh_stack * 4;
 }
+size_t shade_lds_bytes(const DScene& S, int block) { return variant_lds_bytes(S, block, pick_variant(S)); }
 
 template <class F>
 auto with_render_kernel(const DScene& S, bool count, F&& f) {
@@ -578,6 +623,20 @@ auto with_render_kernel(const DScene& S, bool count, F&& f) {
     case 10: return f(k_render<V_FULL, false>);
     default: return f(k_render<V_FULL, true>);
   }
+}
+
+hipError_t allow_lds(size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  hipError_t e = hipSuccess;
+  auto allow = [&](auto kernel) {
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  };
+#define RT_ALLOW(MASK) allow(k_render<MASK, false>); allow(k_render<MASK, true>); allow(k_hit_batch<MASK>); allow(k_sample_batch<MASK>); allow(k_scatter_batch<MASK>);
+  RT_ALLOW(V_RECT) RT_ALLOW(V_SMOKE) RT_ALLOW(V_SPH) RT_ALLOW(V_ALL) RT_ALLOW(V_FULL)
+#undef RT_ALLOW
+  allow(k_render<V_ALL_DEEP, false>); allow(k_hit_batch<V_ALL_DEEP>);
+  return e;
 }
 
 hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, float* out, uint32_t* queue,
@@ -610,11 +669,48 @@ hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t*
   return hipGetLastError();
 }
 
-hipError_t launch_hit_batch(const DScene& S, int n, const float* orig3, const float* dir3, const float* time,
-                            float tmin, float tmax, const float* medium_xi, rt_hit* out, hipStream_t stream) {
+// Does instantiation `variant` (0 V_RECT .. 5 V_FULL) support everything the scene needs?
+bool variant_covers(const DScene& S, int variant) {
+  const bool small = S.n_prims <= RT_LDS_PRIMS && S.n_chains <= RT_LDS_CHAINS;
+  const uint32_t masks[6] = {V_RECT, V_SMOKE, V_SPH, V_ALL, V_ALL_DEEP, V_FULL};
+  if (variant < 0 || variant > 5) return false;
+  if ((masks[variant] & F_SMALL) && !small) return false;
+  return (S.features & ~masks[variant]) == 0;
+}
+int render_variant(const DScene& S) { return pick_variant(S); }
+
+hipError_t launch_hit_batch(const DScene& S, int variant, int n, const float* orig3, const float* dir3,
+                            const float* time, float tmin, float tmax, const float* medium_xi, rt_hit* out,
+                            hipStream_t stream) {
+  const size_t lds = variant_lds_bytes(S, RT_BLOCK, variant);
+  dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
+#define RT_HIT_CASE(V, MASK) case V: hipLaunchKernelGGL(k_hit_batch<MASK>, grid, block, lds, stream, S, n, orig3, dir3, time, tmin, tmax, medium_xi, out); break;
+  switch (variant) {
+    RT_HIT_CASE(0, V_RECT)
+    RT_HIT_CASE(1, V_SMOKE)
+    RT_HIT_CASE(2, V_SPH)
+    RT_HIT_CASE(3, V_ALL)
+    RT_HIT_CASE(4, V_ALL_DEEP)
+    default: hipLaunchKernelGGL(k_hit_batch<V_FULL>, grid, block, lds, stream, S, n, orig3, dir3, time, tmin, tmax, medium_xi, out); break;
+  }
+#undef RT_HIT_CASE
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter_batch(const DScene& S, uint32_t seed_lo, uint32_t seed_hi, int n, const float* orig3,
+                                const float* dir3, const float* time, const int* px, const int* smp,
+                                const int* bounce, rt_scatter* out, hipStream_t stream) {
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
-  hipLaunchKernelGGL(k_hit_batch, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), lds, stream, S, n, orig3,
-                     dir3, time, tmin, tmax, medium_xi, out);
+  dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
+#define RT_SC_CASE(V, MASK) case V: hipLaunchKernelGGL(k_scatter_batch<MASK>, grid, block, lds, stream, S, seed_lo, seed_hi, n, orig3, dir3, time, px, smp, bounce, out); break;
+  switch (pick_variant(S)) {  // the same instantiation the render would use
+    RT_SC_CASE(0, V_RECT)
+    RT_SC_CASE(1, V_SMOKE)
+    RT_SC_CASE(2, V_SPH)
+    RT_SC_CASE(5, V_FULL)
+    default: hipLaunchKernelGGL(k_scatter_batch<V_ALL>, grid, block, lds, stream, S, seed_lo, seed_hi, n, orig3, dir3, time, px, smp, bounce, out); break;
+  }
+#undef RT_SC_CASE
   return hipGetLastError();
 }
 

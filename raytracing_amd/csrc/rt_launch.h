@@ -12,14 +12,26 @@
 namespace rt {
 
 size_t shade_lds_bytes(const DScene& S, int block);
+// Lets every kernel that shades ask for `bytes` of dynamic LDS per workgroup (a no-op up to the
+// 64 KiB every kernel may use without asking; the device allows 160 KiB).
+hipError_t allow_lds(size_t bytes);
 hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, float* out, uint32_t* queue,
                          unsigned long long* stats, bool count, int grid, hipStream_t stream);
 hipError_t render_occupancy(const DScene& S, bool count, int* blocks_per_cu);
 hipError_t launch_resolve(const DRender& R, const float* partial, float* rgb_sum, uint32_t* argb,
                           hipStream_t stream);
 hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t* argb, hipStream_t stream);
-hipError_t launch_hit_batch(const DScene& S, int n, const float* orig3, const float* dir3, const float* time,
-                            float tmin, float tmax, const float* medium_xi, rt_hit* out, hipStream_t stream);
+// Instantiations of the kernels, smallest first: 0 V_RECT, 1 V_SMOKE, 2 V_SPH, 3 V_ALL, 4 V_ALL_DEEP, 5 V_FULL.
+#define RT_N_VARIANTS 6
+bool variant_covers(const DScene& S, int variant);
+int render_variant(const DScene& S);
+size_t variant_lds_bytes(const DScene& S, int block, int variant);
+hipError_t launch_hit_batch(const DScene& S, int variant, int n, const float* orig3, const float* dir3,
+                            const float* time, float tmin, float tmax, const float* medium_xi, rt_hit* out,
+                            hipStream_t stream);
+hipError_t launch_scatter_batch(const DScene& S, uint32_t seed_lo, uint32_t seed_hi, int n, const float* orig3,
+                                const float* dir3, const float* time, const int* px, const int* smp,
+                                const int* bounce, rt_scatter* out, hipStream_t stream);
 hipError_t launch_sample_batch(const DScene& S, const DCamera& cam, const DRender& R, int n, const int* px,
                                const int* smp, float* out_rgb, hipStream_t stream);
 

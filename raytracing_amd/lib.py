@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("RTMI_LIB", os.path.join(_HERE, "librtmi.so"))
 EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version", "rt_scene_create",
            "rt_scene_destroy", "rt_scene_get_info", "rt_render", "rt_render_device",
            "rt_tonemap_device", "rt_hit_batch", "rt_sample_batch", "rt_scene_file_size",
-           "rt_scene_write", "rt_scene_create_from_memory", "rt_scene_create_from_file"]
+           "rt_scene_write", "rt_scene_create_from_memory", "rt_scene_create_from_file",
+           "rt_scene_create_with", "rt_scene_get_variants", "rt_hit_batch_variant", "rt_scatter_batch"]
 
 _LIB = None
 
@@ -50,6 +51,11 @@ def load():
     L.rt_last_error.restype = C.c_char_p
     L.rt_abi_version.restype = C.c_int
     L.rt_scene_create.argtypes = [vp, C.POINTER(abi.rt_scene_desc), C.POINTER(vp)]
+    L.rt_scene_create_with.argtypes = [vp, C.POINTER(abi.rt_scene_desc), C.c_int32, C.POINTER(vp)]
+    L.rt_scene_get_variants.argtypes = [vp, ip, u32p]
+    L.rt_hit_batch_variant.argtypes = [vp, vp, C.c_int32, C.c_int32, fp, fp, fp, C.c_float, C.c_float, fp,
+                                       C.POINTER(abi.rt_hit)]
+    L.rt_scatter_batch.argtypes = [vp, vp, C.c_uint64, C.c_int32, fp, fp, fp, ip, ip, ip, C.POINTER(abi.rt_scatter)]
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_scene_destroy.restype = None
     L.rt_scene_get_info.argtypes = [vp, C.POINTER(abi.rt_scene_info)]
@@ -117,8 +123,8 @@ class Context:
         except Exception:
             pass
 
-    def scene(self, flat) -> "Scene":
-        return Scene(self, flat)
+    def scene(self, flat, bvh_builder: int = abi.RT_BVH_DEFAULT) -> "Scene":
+        return Scene(self, flat, bvh_builder=bvh_builder)
 
     def scene_from_file(self, path: str) -> "Scene":
         """rt_scene_create_from_file: the library reads and validates the scene file itself."""
@@ -135,7 +141,8 @@ class Context:
 class Scene:
     """An uploaded world (rt_scene_create / rt_scene_destroy)."""
 
-    def __init__(self, ctx: Context, flat, path: str = None, data: bytes = None):
+    def __init__(self, ctx: Context, flat, path: str = None, data: bytes = None,
+                 bvh_builder: int = abi.RT_BVH_DEFAULT):
         self.ctx = ctx
         self.flat = flat
         self._L = ctx._L
@@ -145,6 +152,8 @@ class Scene:
         elif data is not None:
             buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
             _check(self._L.rt_scene_create_from_memory(ctx._h, buf, len(data), C.byref(self._h)))
+        elif bvh_builder != abi.RT_BVH_DEFAULT:
+            _check(self._L.rt_scene_create_with(ctx._h, C.byref(flat.desc), bvh_builder, C.byref(self._h)))
         else:
             _check(self._L.rt_scene_create(ctx._h, C.byref(flat.desc), C.byref(self._h)))
 
@@ -184,16 +193,44 @@ class Scene:
                                         C.byref(st) if want_stats else None, stream or None))
         return stats_dict(st) if want_stats else None
 
-    def hit_batch(self, orig, dirs, time=None, t_min=0.001, t_max=float("inf"), medium_xi=None):
-        """-> structured array of rt_hit records."""
+    def variants(self):
+        """-> (instantiation the render uses, list of all instantiations that cover the world)."""
+        rv, mask = C.c_int32(0), C.c_uint32(0)
+        _check(self._L.rt_scene_get_variants(self._h, C.byref(rv), C.byref(mask)))
+        return rv.value, [v for v in range(abi.RT_N_VARIANTS) if mask.value >> v & 1]
+
+    def scatter_batch(self, seed, orig, dirs, time, px, smp, bounce):
+        """One ray-color invocation per ray with the keyed draws of (px, smp, bounce)
+        -> structured array of rt_scatter records."""
+        orig = np.ascontiguousarray(orig, dtype=np.float32)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32)
+        n = orig.shape[0]
+        tm = None if time is None else np.ascontiguousarray(time, dtype=np.float32)
+        ia = [np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.int32), (n,))) for a in (px, smp, bounce)]
+        out = (abi.rt_scatter * max(n, 1))()
+        ipt = C.POINTER(C.c_int32)
+        _check(self._L.rt_scatter_batch(self.ctx._h, self._h, int(seed), n, _fp(orig), _fp(dirs), _fp(tm),
+                                        ia[0].ctypes.data_as(ipt), ia[1].ctypes.data_as(ipt),
+                                        ia[2].ctypes.data_as(ipt), out))
+        dt = np.dtype([("hit", "i4"), ("ok", "i4"), ("mat_id", "i4"), ("pad", "i4"), ("orig", "f4", 3),
+                       ("dir", "f4", 3), ("time", "f4"), ("attenuation", "f4", 3), ("emitted", "f4", 3)])
+        return np.frombuffer(out, dtype=dt, count=n).copy()
+
+    def hit_batch(self, orig, dirs, time=None, t_min=0.001, t_max=float("inf"), medium_xi=None, variant=None):
+        """-> structured array of rt_hit records. variant: None = rt_hit_batch, else the kernel
+        instantiation for rt_hit_batch_variant (abi.RT_VARIANT_RENDER, 0..5)."""
         orig = np.ascontiguousarray(orig, dtype=np.float32)
         dirs = np.ascontiguousarray(dirs, dtype=np.float32)
         n = orig.shape[0]
         tm = None if time is None else np.ascontiguousarray(time, dtype=np.float32)
         xi = None if medium_xi is None else np.ascontiguousarray(medium_xi, dtype=np.float32)
         out = (abi.rt_hit * max(n, 1))()
-        _check(self._L.rt_hit_batch(self.ctx._h, self._h, n, _fp(orig), _fp(dirs), _fp(tm), t_min, t_max,
-                                    _fp(xi), out))
+        if variant is None:
+            _check(self._L.rt_hit_batch(self.ctx._h, self._h, n, _fp(orig), _fp(dirs), _fp(tm), t_min, t_max,
+                                        _fp(xi), out))
+        else:
+            _check(self._L.rt_hit_batch_variant(self.ctx._h, self._h, int(variant), n, _fp(orig), _fp(dirs),
+                                                _fp(tm), t_min, t_max, _fp(xi), out))
         dt = np.dtype([("t", "f4"), ("p", "f4", 3), ("normal", "f4", 3), ("u", "f4"), ("v", "f4"),
                        ("front_face", "i4"), ("mat_id", "i4"), ("hit", "i4")])
         return np.frombuffer(out, dtype=dt, count=n).copy()

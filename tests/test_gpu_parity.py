@@ -1,9 +1,12 @@
 """GPU parity: the HIP path (through the C ABI of librtmi.so) against the CPU oracle.
 
 Tolerances (north star: hit records within 1e-5 relative; renders within Monte Carlo error):
-  * t:  |dt| <= 1e-5 * max(|t|, |orig|/|dir|). The floor matters only for rays that start within
-        rounding distance of a surface under a rotate-y/translate chain: the rotated origin is
-        held in FP32, so t cannot be resolved relative to t itself there.
+  * t:  |dt| <= 1e-5 * max(|t|, |orig|/|dir|), i.e. an error in t counts when it moves the hit
+        point by more than 1e-5 of the point's own magnitude. Seven of the eight worlds also meet
+        the plain |dt| <= 1e-5 |t| (observed maxima 6e-8 .. 3e-6, profiles/r02_parity_stats.txt);
+        the Cornell box does not for rays that start on a rotated block and hit again within a
+        fraction of a unit (t ~ 0.01 with coordinates ~ 500: the chain-space origin is held in
+        FP32, 3e-5 absolute), where its plain relative error reaches 3e-3.
   * p, normal: Euclidean error <= 1e-5 * max(norm, 1);  u, v: absolute 1e-5.
   * hit / front-face / material: exact, except a knife-edge budget of 1e-4 of the rays.
 """
@@ -20,6 +23,12 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SEED = 0x5EED0001
 TOL = 1e-5
+# Share of a batch that may disagree outright because a comparison sits on a knife edge (a ray that
+# grazes an edge, an exact tie): set from what is observed on the MI355X (profiles/r02_parity_stats.txt).
+# Observed: 0 of 20 000 probe rays in every world; path rays 4 of 9 249 (Cornell box, rays leaving
+# the rotated blocks along their faces), 0 elsewhere; scattered rays at most 3 of 12 301.
+KNIFE_PROBE = 5e-5
+KNIFE_PATH = 6e-4
 
 
 def _uv_exempt(name, flat):
@@ -31,7 +40,7 @@ def _uv_exempt(name, flat):
     return {int(flat.a_prim_mat[0])} if name == "final-scene" else set()
 
 
-def _check_hits(dev, orc, o32, d32, knife_budget, uv_exempt=()):
+def _check_hits(dev, orc, o32, d32, knife_budget, uv_exempt=(), label=None):
     e = compare_hits(dev, orc, d32)
     for m in uv_exempt:
         e["uv"] = np.where(orc[:, 10].astype(int) == m, 0.0, e["uv"])
@@ -41,6 +50,13 @@ def _check_hits(dev, orc, o32, d32, knife_budget, uv_exempt=()):
     t_err = np.abs(dev["t"] - orc[:, 0]) / np.maximum(np.abs(orc[:, 0]), t_floor)
     bad = both & ((t_err > TOL) | (e["p"] > TOL) | (e["n"] > TOL) | (e["uv"] > TOL) | e["front"] | e["mat"])
     n_bad = int(bad.sum()) + e["hit_mismatch"]
+    good = both & ~bad
+    if label and good.any():
+        q = lambda a: float(np.quantile(a[good], 0.9999))
+        print(f"[parity] {label}: {n} rays, {int(both.sum())} hits; knife-edge {n_bad} (hit/miss {e['hit_mismatch']}); "
+              f"t relative to |t| alone: 99.99th pct {q(e['t']):.2e} max {e['t'][good].max():.2e}; "
+              f"99.99th pct t {q(t_err):.2e} p {q(e['p']):.2e} n {q(e['n']):.2e} uv {q(e['uv']):.2e}; "
+              f"max t {t_err[good].max():.2e} p {e['p'][good].max():.2e} n {e['n'][good].max():.2e} uv {e['uv'][good].max():.2e}")
     if n_bad > max(1, int(knife_budget * n)):
         for i in np.nonzero(bad)[0][:8]:
             print(f"ray {i}: o {o32[i]} d {d32[i]} t_err {t_err[i]:.3g} p {e['p'][i]:.3g} n {e['n'][i]:.3g} "
@@ -63,17 +79,17 @@ def test_hit_records_probe_rays(gpu_ctx, oracle, name):
     dev = sc.hit_batch(o, d, tm, medium_xi=xi)
     orc = oracle.hit_batch(flat, o, d, tm, medium_xi=xi)
     assert int(orc[:, 11].sum()) > n // 20
-    _check_hits(dev, orc, o, d, 1e-4, _uv_exempt(name, flat))
+    _check_hits(dev, orc, o, d, KNIFE_PROBE, _uv_exempt(name, flat), label=f"{name} probe rays")
     # media skipped on both sides (medium_xi = NULL)
     if nm:
         dev = sc.hit_batch(o, d, tm)
         orc = oracle.hit_batch(flat, o, d, tm)
-        _check_hits(dev, orc, o, d, 1e-4, _uv_exempt(name, flat))
+        _check_hits(dev, orc, o, d, KNIFE_PROBE, _uv_exempt(name, flat))
     sc.close()
 
 
 @pytest.mark.parametrize("name", ["random-scene", "final-scene"])
-def test_both_tree_builders_give_the_same_records(gpu_ctx, name, monkeypatch):
+def test_both_tree_builders_give_the_same_records(gpu_ctx, name):
     """The closest hit does not depend on the shape of the tree (exact ties are settled by scan
     order, not by visiting order): the host's surface-area tree and the device's Morton tree must
     return identical records, bit for bit, and identical frames."""
@@ -84,19 +100,16 @@ def test_both_tree_builders_give_the_same_records(gpu_ctx, name, monkeypatch):
     xi = np.random.default_rng(4).random((n, max(nm, 1))).astype(np.float32) if nm else None
     p = abi.make_params(24, 16, 3, 50, cfg["background"], seed=5)
     out = []
-    for morton in (False, True):
-        if morton:
-            monkeypatch.setenv("RTMI_BVH_MORTON", "1")
-        else:
-            monkeypatch.delenv("RTMI_BVH_MORTON", raising=False)
-        sc = gpu_ctx.scene(flat)
+    for builder in (abi.RT_BVH_HOST_SAH, abi.RT_BVH_DEVICE, abi.RT_BVH_DEFAULT):
+        sc = gpu_ctx.scene(flat, bvh_builder=builder)
         hits = sc.hit_batch(o, d, tm, medium_xi=xi)
         rgb, argb, st = sc.render(cam, p)
         out.append((hits.tobytes(), rgb.tobytes(), st["rays"]))
         sc.close()
-    assert out[0][0] == out[1][0]
-    assert out[0][1] == out[1][1]
-    assert out[0][2] == out[1][2]
+    for k in (1, 2):
+        assert out[0][0] == out[k][0]
+        assert out[0][1] == out[k][1]
+        assert out[0][2] == out[k][2]
 
 
 @pytest.mark.parametrize("name", ALL_SCENES)
@@ -121,7 +134,45 @@ def test_hit_records_path_rays(gpu_ctx, oracle, name):
     xi = np.array(xis, dtype=np.float32) if nm else None
     dev = sc.hit_batch(o32, d32, t32, medium_xi=xi)
     orc = oracle.hit_batch(flat, o32, d32, t32, medium_xi=xi)
-    _check_hits(dev, orc, o32, d32, 1e-3, _uv_exempt(name, flat))
+    _check_hits(dev, orc, o32, d32, KNIFE_PATH, _uv_exempt(name, flat), label=f"{name} path rays")
+    sc.close()
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_scatter_matches_the_next_path_ray(gpu_ctx, oracle, name):
+    """(scatter mat r rec) of materials.clj on the device, bounce by bounce: the oracle lists the rays
+    one (pixel, sample) path hands to `hit`; given ray b and the keys (pixel, sample, bounce b) the
+    device must produce ray b+1 (origin, un-normalised direction, time), and must end the path
+    (miss, light, or absorbed metal bounce) where the oracle's list ends."""
+    cfg, flat, cam = scene_bundle(name)
+    sc = gpu_ctx.scene(flat)
+    W = H = 64
+    p = abi.make_params(W, H, 4, 50, cfg["background"], seed=SEED)
+    rng = np.random.default_rng(15)
+    R, PX, SMP, B, NXT, LAST = [], [], [], [], [], []
+    for _ in range(1500):
+        px, smp = int(rng.integers(0, W * H)), int(rng.integers(0, 4000))
+        r = oracle.path_rays(flat, cam, p, px, smp)
+        for b in range(len(r)):
+            R.append(r[b]); PX.append(px); SMP.append(smp); B.append(b)
+            last = b + 1 == len(r)
+            NXT.append(r[b] if last else r[b + 1]); LAST.append(last and len(r) < 50)
+    R, NXT, LAST = np.array(R), np.array(NXT), np.array(LAST)
+    dev = sc.scatter_batch(SEED, R[:, 0:3], R[:, 3:6], R[:, 6], PX, SMP, B)
+    cont = (dev["hit"] == 1) & (dev["ok"] == 1)
+    ends_wrong = cont == LAST                      # continues where the oracle ended, or the reverse
+    full_depth = np.array(B) == 49                  # the 50th ray-color call: the oracle's list ends by depth
+    ends_wrong &= ~full_depth
+    both = cont & ~LAST & ~full_depth
+    eo = np.linalg.norm(dev["orig"] - NXT[:, 0:3], axis=1) / np.maximum(np.linalg.norm(NXT[:, 0:3], axis=1), 1.0)
+    ed = np.linalg.norm(dev["dir"] - NXT[:, 3:6], axis=1) / np.maximum(np.linalg.norm(NXT[:, 3:6], axis=1), 1.0)
+    et = np.abs(dev["time"] - NXT[:, 6])
+    bad = both & ((eo > TOL) | (ed > TOL) | (et > 1e-6))
+    n_bad = int(bad.sum()) + int(ends_wrong.sum())
+    print(f"[parity] {name} scatter: {len(R)} bounces, {int(both.sum())} continued on both sides; knife-edge {n_bad} "
+          f"(ends differ {int(ends_wrong.sum())}); 99.99th pct orig {np.quantile(eo[both & ~bad], 0.9999):.2e} "
+          f"dir {np.quantile(ed[both & ~bad], 0.9999):.2e}; max orig {eo[both & ~bad].max():.2e} dir {ed[both & ~bad].max():.2e}")
+    assert n_bad <= max(1, int(KNIFE_PATH * len(R))), f"{n_bad} of {len(R)} bounces disagree"
     sc.close()
 
 
@@ -423,3 +474,25 @@ def test_convergence_independent_streams(gpu_ctx, oracle):
         assert frac_out < 0.03
         assert abs(md.mean() - mo.mean()) < 4 * np.sqrt((se ** 2).mean() / se.size) + 1e-4
         sc.close()
+
+
+def test_main_samples_10_is_the_reference_default(gpu_ctx, oracle):
+    """`(-main :samples 10)` (core.clj:50-59: 200x200, aspect 1.0, depth 50, :final-scene) through
+    raytracing_amd.core.main on the GPU, against the oracle rendering the same request with the
+    same keyed random stream. No JVM exists here, so the oracle stands in for the Clojure path."""
+    from raytracing_amd import core
+    argb, st = core.main(samples=10)
+    assert argb.shape == (200, 200) and st["samples"] == 200 * 200 * 10
+    cfg, flat = core.setup("final-scene", 1)
+    cam = core.build_camera(cfg, 1.0)
+    p = abi.make_params(200, 200, 10, 50, cfg["background"], seed=0x5EED0001)
+    orgb, oargb, orays = oracle.render(flat, cam, p, nthreads=8)
+    assert abs(st["rays"] - orays) <= 0.005 * orays
+    ch = np.array([16, 8, 0])[:, None, None]
+    diff = np.abs(((argb >> ch) & 255).astype(int) - ((oargb >> ch) & 255).astype(int)).max(axis=0)
+    # a pixel differs by more than one 8-bit step only where one of its 10 paths took another branch
+    print(f"[parity] main(samples=10): {int((diff > 1).sum())} of 40000 pixels differ by more than one step, "
+          f"{int((diff == 1).sum())} by one; rays {st['rays']} vs {orays}")
+    assert (diff > 1).mean() <= 0.02
+    img = core.to_buffered_image(argb)
+    assert img.shape == (275, 220) and (img[230 - 0, :200] == (argb[0] & 0xFFFFFF)).all()   # core.clj:123-126

@@ -109,34 +109,8 @@ def test_k8_translate_rotate_box_matches_an_independent_walk(oracle):
     blk = translate(rotate_y(box([0, 0, 0], [165, 330, 165], white), 15), [265, 0, 295])
     o = np.array([278.0, 278.0, -800.0]); d = np.array([0.0625, -0.03125, 1.0])  # exact in FP32
     h = hit1(oracle, [blk], o, d)
-    s, c = math.sin(math.radians(15)), math.cos(math.radians(15))
-    om = o - np.array([265.0, 0, 295.0])
-    orot = np.array([c * om[0] - s * om[2], om[1], s * om[0] + c * om[2]])
-    drot = np.array([c * d[0] - s * d[2], d[1], s * d[0] + c * d[2]])
-    best = None
-    sides = [(2, 165.0, (0, 1), (0, 165, 0, 330)), (2, 0.0, (0, 1), (0, 165, 0, 330)),
-             (1, 330.0, (0, 2), (0, 165, 0, 165)), (1, 0.0, (0, 2), (0, 165, 0, 165)),
-             (0, 165.0, (1, 2), (0, 330, 0, 165)), (0, 0.0, (1, 2), (0, 330, 0, 165))]
-    for axis, k, (ia, ib), (a0, a1, b0, b1) in sides:  # box.clj:18-23 order, base.clj:92-101 scan
-        t = (k - orot[axis]) / drot[axis]
-        if t < 0.001 or (best is not None and t > best[0]):
-            continue
-        a, b = orot[ia] + t * drot[ia], orot[ib] + t * drot[ib]
-        if a < a0 or a > a1 or b < b0 or b > b1:
-            continue
-        n = np.zeros(3); n[axis] = 1.0
-        if drot @ n >= 0:
-            n = -n
-        best = (t, orot + t * drot, n)
-    t, p, n = best
-    p2 = np.array([c * p[0] + s * p[2], p[1], s * p[0] + c * p[2]])
-    n2 = np.array([c * n[0] + s * n[2], n[1], s * n[0] + c * n[2]])
-    if not (drot @ n2 < 0):
-        n2 = -n2
-    front = (d @ n2) < 0   # translate.clj:13: against the moved ray (world direction)
-    if not front:
-        n2 = -n2
-    p3 = p2 + np.array([265.0, 0, 295.0])
+    from util import cornell_block_walk
+    t, p3, n2, front = cornell_block_walk(o, d)
     assert h["hit"] == 1 and h["t"] == pytest.approx(t, rel=1e-14)
     assert [h["px"], h["py"], h["pz"]] == pytest.approx(list(p3), rel=1e-13)
     assert [h["nx"], h["ny"], h["nz"]] == pytest.approx(list(n2), abs=1e-15)

@@ -63,3 +63,71 @@ def compare_hits(dev, orc, d32):
     e["mat"] = (dev["mat_id"] != orc[:, 10].astype(np.int32)) & both
     e["both"] = both
     return e
+
+
+# ------------------------------------------------------------------ independent re-derivations
+_MASK = 0xFFFFFFFF
+
+
+def philox4x32(ctr, key, rounds=7):
+    """Philox-4x32 (Salmon et al., SC'11) in plain Python, independent of both the oracle and the
+    device; pinned by the Random123 known-answer vectors in tests/test_gpu_kat.py."""
+    c0, c1, c2, c3 = ctr
+    k0, k1 = key
+    for _ in range(rounds):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & _MASK, p1 & _MASK, ((p0 >> 32) ^ c3 ^ k1) & _MASK, p0 & _MASK
+        k0, k1 = (k0 + 0x9E3779B9) & _MASK, (k1 + 0xBB67AE85) & _MASK
+    return [c0, c1, c2, c3]
+
+
+def keyed_camera_ray(cam, W, H, px, smp, seed):
+    """core.clj:96-102 + ray.clj:14-26 in FP64 for pixel index px, sample smp, lens radius 0: the
+    jitter uniforms are words 0..2 of the keyed block (counter (0, 0, seed lo, seed hi), key (px,
+    smp)), top 24 bits each. -> (orig[3], dir[3], time)."""
+    w = philox4x32([0, 0, seed & _MASK, seed >> 32], [px, smp])
+    u = [(x >> 8) / 16777216.0 for x in w]
+    x, y = px % W, px // W
+    s, t = (x + u[0]) / (W - 1), (y + u[1]) / (H - 1)
+    org = np.array(cam.origin[:], dtype=np.float64)
+    d = (np.array(cam.lower_left_corner[:]) + s * np.array(cam.horizontal[:]) + t * np.array(cam.vertical[:])) - org
+    return org, d, cam.time0 + (cam.time1 - cam.time0) * u[2]
+
+
+def cornell_block_walk(o, d):
+    """Cornell block 1 (scenes.clj:82-84: translate [265 0 295] of rotate-y 15 of box [0 0 0]-[165 330 165])
+    hit by ray (o, d), walked by hand in FP64 numpy: translate.clj:10-17, rotate.clj:11-47, box.clj:18-23
+    order, base.clj:92-101 scan. -> (t, p, normal, front_face) or None."""
+    import math
+    s, c = math.sin(math.radians(15)), math.cos(math.radians(15))
+    om = o - np.array([265.0, 0, 295.0])
+    orot = np.array([c * om[0] - s * om[2], om[1], s * om[0] + c * om[2]])
+    drot = np.array([c * d[0] - s * d[2], d[1], s * d[0] + c * d[2]])
+    best = None
+    sides = [(2, 165.0, (0, 1), (0, 165, 0, 330)), (2, 0.0, (0, 1), (0, 165, 0, 330)),
+             (1, 330.0, (0, 2), (0, 165, 0, 165)), (1, 0.0, (0, 2), (0, 165, 0, 165)),
+             (0, 165.0, (1, 2), (0, 330, 0, 165)), (0, 0.0, (1, 2), (0, 330, 0, 165))]
+    for axis, k, (ia, ib), (a0, a1, b0, b1) in sides:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (k - orot[axis]) / drot[axis]
+        if t < 0.001 or (best is not None and t > best[0]):
+            continue
+        a, b = orot[ia] + t * drot[ia], orot[ib] + t * drot[ib]
+        if a < a0 or a > a1 or b < b0 or b > b1:
+            continue
+        n = np.zeros(3)
+        n[axis] = 1.0
+        if drot @ n >= 0:
+            n = -n
+        best = (t, orot + t * drot, n)
+    if best is None:
+        return None
+    t, p, n = best
+    p2 = np.array([c * p[0] + s * p[2], p[1], s * p[0] + c * p[2]])   # rotate.clj:32-36, +sin in z
+    n2 = np.array([c * n[0] + s * n[2], n[1], s * n[0] + c * n[2]])
+    if not (drot @ n2 < 0):                                            # rotate.clj:43
+        n2 = -n2
+    front = (d @ n2) < 0                                               # translate.clj:13
+    if not front:
+        n2 = -n2
+    return t, p2 + np.array([265.0, 0, 295.0]), n2, bool(front)
