@@ -15,7 +15,9 @@
  *   - return value: 0 = ok, negative = error (RT_ERR_*); rt_last_error() returns a
  *     thread-local, library-owned message for the last failing call on this thread.
  *   - no exceptions, no aborts, no callbacks cross this boundary.
- *   - calls on one context must be serialised by the caller.
+ *   - calls on one context must be serialised by the caller, and a context has ONE render in
+ *     flight at a time: renders share the context's work queue and partial sums, so a second
+ *     rt_render_device must not be enqueued (on any stream) before the first has finished.
  *   - there is no CPU fallback: without a HIP device rt_init fails with RT_ERR_HIP.
  */
 #ifndef RTMI_H
@@ -230,6 +232,20 @@ int rt_render(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, const rt
 int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam,
                      const rt_params* params, float* d_rgb_sum, uint32_t* d_argb,
                      rt_stats* stats, void* hip_stream);
+
+/* rt_render_device for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc). It has no counterpart in the reference.
+ * The render's scratch (work-queue heads, counters, one 12-byte partial sum per work item) lives in
+ * a fixed 32 MiB device array inside the library instead of in buffers allocated on demand, so the
+ * call allocates and frees nothing and never synchronises. Results are bit-identical to
+ * rt_render_device's. Limits: at most 2 795 861 work items per call (work items = owned 8x8 tiles
+ * x 64 x sample chunks, where spp <= 32 gives spp chunks, spp <= 128 gives 32 and larger spp up to
+ * 112: e.g. 256x256 at any spp, 1024x1024 up to 2 spp per call); larger requests are refused with
+ * RT_ERR_UNSUPPORTED. No statistics (RT_FLAG_COUNTERS is refused). All calls on one GPU share the
+ * array: two of them in flight at once on that GPU (any streams, any contexts) race. */
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam,
+                             const rt_params* params, float* d_rgb_sum, uint32_t* d_argb,
+                             void* hip_stream);
 
 /* The post-process of core.clj:106-108,118,121-122 alone, device buffers: used on the root
  * rank after per-GPU sums have been combined. `spp_total` is the divisor. */

@@ -67,6 +67,7 @@ struct rt_ctx {
   int n_cu = 0;
   int clock_khz = 0;
   size_t lds_max = 65536;  // LDS a workgroup may ask for on this device
+  unsigned char* scratch = nullptr;  // this device's copy of the file-scope scratch array (rt_render_device_noalloc)
   // reusable device workspace
   uint32_t* d_queue = nullptr;              // the heads of the work-item queue (RT_QUEUE_HEADS lines)
   unsigned long long* d_stats = nullptr;    // 2 + RT_EV_COUNT words
@@ -343,33 +344,34 @@ int fill_render(const rt_scene* sc, const rt_camera* cam, const rt_params* p, DR
   // together. Items must also be short against the job: waves of one SIMD do not progress at the
   // same rate, and a slow wave is still inside the item it took early when the fast ones have
   // emptied the queue (with 24 chunks of 33 samples an eighth-of-the-image shard lost 12 %).
-  {
-    std::vector<int> sizes;
+  {  // (fixed arrays: this runs on the entry point that may not allocate)
+    int sizes[RT_MAX_CHUNKS + 64];
+    int n_sizes = 0;
     const int spp = p->spp;
     if (spp <= 128) {  // too few samples for tiers: up to 32 equal chunks
       const int n = std::min(spp, 32), sz = (spp + n - 1) / n;
-      for (int left = spp; left > 0; left -= sz) sizes.push_back(std::min(sz, left));
+      for (int left = spp; left > 0; left -= sz) sizes[n_sizes++] = std::min(sz, left);
     } else {
       const int tier_count[5] = {8, 8, 8, 8, 16};
       const int tier_permille[5] = {12, 6, 3, 2, 1};  // of spp, per chunk
-      std::vector<int> tail;
-      int tail_sum = 0;
+      int tail[48];
+      int n_tail = 0, tail_first = 0, tail_sum = 0;
       for (int t = 0; t < 5; ++t)
         for (int k = 0; k < tier_count[t]; ++k) {
           int sz = std::max(1, (int)((long long)spp * tier_permille[t] / 1000));
-          tail.push_back(sz);
+          tail[n_tail++] = sz;
           tail_sum += sz;
         }
       int rem = spp - tail_sum;  // samples of the equal chunks
-      while (rem <= 0) { tail_sum -= tail.front(); tail.erase(tail.begin()); rem = spp - tail_sum; }
+      while (rem <= 0) { tail_sum -= tail[tail_first++]; rem = spp - tail_sum; }
       const int big = (rem + 63) / 64;
-      for (int left = rem; left > 0; left -= big) sizes.push_back(std::min(big, left));
-      sizes.insert(sizes.end(), tail.begin(), tail.end());
+      for (int left = rem; left > 0; left -= big) sizes[n_sizes++] = std::min(big, left);
+      for (int k = tail_first; k < n_tail; ++k) sizes[n_sizes++] = tail[k];
     }
-    if ((int)sizes.size() > RT_MAX_CHUNKS) return fail(RT_ERR_ARG, "internal: %zu chunks", sizes.size());
-    R.n_chunks = (int)sizes.size();
+    if (n_sizes > RT_MAX_CHUNKS) return fail(RT_ERR_ARG, "internal: %d chunks", n_sizes);
+    R.n_chunks = n_sizes;
     int at = 0;
-    for (int c = 0; c < R.n_chunks; ++c) { R.chunk_start[c] = at; at += sizes[(size_t)c]; }
+    for (int c = 0; c < R.n_chunks; ++c) { R.chunk_start[c] = at; at += sizes[c]; }
     for (int c = R.n_chunks; c <= RT_MAX_CHUNKS; ++c) R.chunk_start[c] = at;  // == spp
   }
   long long n_items = (long long)R.n_owned_tiles * 64 * R.n_chunks;
@@ -403,6 +405,8 @@ extern "C" {
 const char* rt_last_error(void) { return g_err.c_str(); }
 int rt_abi_version(void) { return RTMI_ABI_VERSION; }
 
+static int lookup_scratch(rt_ctx* ctx);
+
 int rt_init(int32_t device_id, rt_ctx** out) {
   if (!out) return fail(RT_ERR_ARG, "out is NULL");
   *out = nullptr;
@@ -416,7 +420,8 @@ int rt_init(int32_t device_id, rt_ctx** out) {
   rt_ctx* ctx = new (std::nothrow) rt_ctx();
   if (!ctx) return fail(RT_ERR_OOM, "out of host memory");
   ctx->device = device_id;
-  const int rc = init_ctx(ctx);
+  int rc = init_ctx(ctx);
+  if (!rc) rc = lookup_scratch(ctx);
   if (rc) {  // whatever was allocated so far goes back; the message of the failing call stays
     rt_shutdown(ctx);
     return rc;
@@ -965,6 +970,39 @@ int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
   return RT_OK;
 }
 
+// Enqueues one render on `stream`: clears the queue heads and counters, launches the path kernel over
+// the persistent grid, resolves the partial sums. `queue`, `d_stats` and `partial` are the scratch
+// buffers of this render (the context's own, or the file-scope array of the entry point that
+// allocates nothing). Synchronises only when `stats` is asked for.
+static int render_enqueue(rt_ctx* ctx, const rt_scene* sc, const DRender& R, const DCamera& C, bool count, uint32_t* queue,
+                          unsigned long long* d_stats, float* partial, float* d_rgb_sum, uint32_t* d_argb,
+                          rt_stats* stats, hipStream_t stream) {
+  HIPCHK(hipMemsetAsync(queue, 0, RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4, stream));
+  HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * (2 + RT_EV_COUNT), stream));
+  // persistent grid: as many workgroups as stay resident, never more than there is work for
+  int grid = ctx->n_cu * sc->blocks_per_cu[count ? 1 : 0];
+  int grid_needed = (R.n_items + RT_BLOCK - 1) / RT_BLOCK;
+  grid = std::max(1, std::min(grid, grid_needed));
+  if (stats) HIPCHK(hipEventRecord(ctx->ev0, stream));
+  if (R.n_items > 0)
+    HIPCHK(launch_render(sc->S, C, R, partial, queue, d_stats, count, grid, stream));
+  if (stats) HIPCHK(hipEventRecord(ctx->ev1, stream));
+  if (d_rgb_sum || d_argb) HIPCHK(launch_resolve(R, partial, d_rgb_sum, d_argb, stream));
+  if (stats) {
+    unsigned long long h[2 + RT_EV_COUNT];
+    HIPCHK(hipMemcpyAsync(h, d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    std::memset(stats, 0, sizeof *stats);
+    stats->samples = h[0];
+    stats->rays = h[1];
+    for (int e = 0; e < RT_EV_COUNT; ++e) stats->events[e] = h[2 + e];
+    stats->kernel_ms = ms;
+  }
+  return RT_OK;
+}
+
 static int render_device_impl(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, float* d_rgb_sum,
                               uint32_t* d_argb, rt_stats* stats, void* hip_stream) {
   if (!ctx || !sc || sc->ctx != ctx) return fail(RT_ERR_ARG, "ctx/scene is NULL or the scene belongs to another context");
@@ -978,37 +1016,61 @@ static int render_device_impl(rt_ctx* ctx, const rt_scene* sc, const rt_camera* 
   const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
   const size_t need = (size_t)std::max(R.n_items, 1) * 3 * sizeof(float);  // one slot per work item
   if (ctx->partial_bytes < need) {
-    HIPCHK(hipStreamSynchronize(stream));
+    // (the whole device: an earlier render on another stream may still be using the old slab)
+    HIPCHK(hipDeviceSynchronize());
     if (ctx->d_partial) HIPCHK(hipFree(ctx->d_partial));
     ctx->d_partial = nullptr;
     ctx->partial_bytes = 0;
     HIPCHK(hipMalloc(&ctx->d_partial, need));
     ctx->partial_bytes = need;
   }
-  HIPCHK(hipMemsetAsync(ctx->d_queue, 0, RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4, stream));
-  HIPCHK(hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (2 + RT_EV_COUNT), stream));
-  // persistent grid: as many workgroups as stay resident, never more than there is work for
-  int grid = ctx->n_cu * sc->blocks_per_cu[count ? 1 : 0];
-  int grid_needed = (R.n_items + RT_BLOCK - 1) / RT_BLOCK;
-  grid = std::max(1, std::min(grid, grid_needed));
-  if (stats) HIPCHK(hipEventRecord(ctx->ev0, stream));
-  if (R.n_items > 0)
-    HIPCHK(launch_render(sc->S, C, R, ctx->d_partial, ctx->d_queue, ctx->d_stats, count, grid, stream));
-  if (stats) HIPCHK(hipEventRecord(ctx->ev1, stream));
-  if (d_rgb_sum || d_argb) HIPCHK(launch_resolve(R, ctx->d_partial, d_rgb_sum, d_argb, stream));
-  if (stats) {
-    unsigned long long h[2 + RT_EV_COUNT];
-    HIPCHK(hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    std::memset(stats, 0, sizeof *stats);
-    stats->samples = h[0];
-    stats->rays = h[1];
-    for (int e = 0; e < RT_EV_COUNT; ++e) stats->events[e] = h[2 + e];
-    stats->kernel_ms = ms;
-  }
+  return render_enqueue(ctx, sc, R, C, count, ctx->d_queue, ctx->d_stats, ctx->d_partial, d_rgb_sum, d_argb, stats, stream);
+}
+
+// ---- the entry point that allocates nothing ------------------------------------------------
+// Scratch of a render = the queue heads, the counters and the partial-sum slab (one 12-byte slot
+// per work item). Here they live in this file-scope device array instead of in buffers the
+// library allocates. Each GPU holds its own copy at its own address (looked up once per device in
+// rt_init and kept in the context); every call on a GPU shares that GPU's copy.
+#define RT_SCRATCH_BYTES (32u << 20)
+#define RT_SCRATCH_QUEUE_OFF 0u       // RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4 = 1024 bytes
+#define RT_SCRATCH_STATS_OFF 1024u    // (2 + RT_EV_COUNT) * 8 bytes
+#define RT_SCRATCH_SLAB_OFF 4096u
+static_assert(RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4 <= RT_SCRATCH_STATS_OFF, "queue heads overlap the counters");
+static_assert(RT_SCRATCH_STATS_OFF + (2 + RT_EV_COUNT) * 8 <= RT_SCRATCH_SLAB_OFF, "counters overlap the slab");
+static __device__ __align__(256) unsigned char scratch[RT_SCRATCH_BYTES];
+
+// Called by rt_init with the context's device current.
+static int lookup_scratch(rt_ctx* ctx) {
+  void* ptr = nullptr;
+  HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+  if (!ptr) return fail(RT_ERR_HIP, "the scratch array has no address on device %d", ctx->device);
+  ctx->scratch = static_cast<unsigned char*>(ptr);
   return RT_OK;
+}
+
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, float* d_rgb_sum,
+                             uint32_t* d_argb, void* hip_stream) {
+  if (!ctx || !sc || sc->ctx != ctx) return fail(RT_ERR_ARG, "ctx/scene is NULL or the scene belongs to another context");
+  if (!ctx->scratch) return fail(RT_ERR_HIP, "the scratch array was not found on device %d", ctx->device);
+  DRender R;
+  int rc = fill_render(sc, cam, p, R);
+  if (rc) return rc;
+  if (p->flags & RT_FLAG_COUNTERS) return fail(RT_ERR_UNSUPPORTED, "rt_render_device_noalloc returns no statistics: RT_FLAG_COUNTERS is refused");
+  const unsigned long long need = (unsigned long long)R.n_items * 3ull * sizeof(float);
+  const unsigned long long room = RT_SCRATCH_BYTES - RT_SCRATCH_SLAB_OFF;
+  if (need > room)
+    return fail(RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: %d work items (%d tiles x 64 pixels x %d sample chunks) need %llu "
+                "bytes of partial sums, the fixed scratch holds %llu (at most %llu work items): render fewer pixels or samples "
+                "per call, or use rt_render_device", R.n_items, R.n_owned_tiles, R.n_chunks, need, room, room / 12ull);
+  HIPCHK(hipSetDevice(ctx->device));
+  DCamera C;
+  fill_camera(cam, p, C);
+  unsigned char* base = ctx->scratch;
+  return render_enqueue(ctx, sc, R, C, false, reinterpret_cast<uint32_t*>(base + RT_SCRATCH_QUEUE_OFF),
+                        reinterpret_cast<unsigned long long*>(base + RT_SCRATCH_STATS_OFF),
+                        reinterpret_cast<float*>(base + RT_SCRATCH_SLAB_OFF), d_rgb_sum, d_argb, nullptr,
+                        static_cast<hipStream_t>(hip_stream));
 }
 
 int rt_render_device(rt_ctx* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, float* d_rgb_sum,

@@ -16,7 +16,8 @@ EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version", "rt_scen
            "rt_scene_destroy", "rt_scene_get_info", "rt_render", "rt_render_device",
            "rt_tonemap_device", "rt_hit_batch", "rt_sample_batch", "rt_scene_file_size",
            "rt_scene_write", "rt_scene_create_from_memory", "rt_scene_create_from_file",
-           "rt_scene_create_with", "rt_scene_get_variants", "rt_hit_batch_variant", "rt_scatter_batch"]
+           "rt_scene_create_with", "rt_scene_get_variants", "rt_hit_batch_variant", "rt_scatter_batch",
+           "rt_render_device_noalloc"]
 
 _LIB = None
 
@@ -63,6 +64,7 @@ def load():
                             C.POINTER(abi.rt_stats)]
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), vp, vp,
                                    C.POINTER(abi.rt_stats), vp]
+    L.rt_render_device_noalloc.argtypes = [vp, vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), vp, vp, vp]
     L.rt_tonemap_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
     L.rt_hit_batch.argtypes = [vp, vp, C.c_int32, fp, fp, fp, C.c_float, C.c_float, fp, C.POINTER(abi.rt_hit)]
     L.rt_sample_batch.argtypes = [vp, vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), C.c_int32,
@@ -192,6 +194,12 @@ class Scene:
                                         d_rgb_sum_ptr or None, d_argb_ptr or None,
                                         C.byref(st) if want_stats else None, stream or None))
         return stats_dict(st) if want_stats else None
+
+    def render_device_noalloc(self, cam, params, d_rgb_sum_ptr: int = 0, d_argb_ptr: int = 0, stream: int = 0):
+        """rt_render_device_noalloc: the same render with its scratch in the library's fixed device
+        array; allocates nothing, returns no statistics, refuses requests beyond the array's size."""
+        _check(self._L.rt_render_device_noalloc(self.ctx._h, self._h, C.byref(cam), C.byref(params),
+                                                d_rgb_sum_ptr or None, d_argb_ptr or None, stream or None))
 
     def variants(self):
         """-> (instantiation the render uses, list of all instantiations that cover the world)."""
