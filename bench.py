@@ -36,8 +36,66 @@ FLOPS_PER_EVENT = {
     "unit_disk_trial": 7, "lambert_scatter": 13, "metal_scatter": 33, "dielectric_scatter": 60,
     "iso_scatter": 0, "light_emit": 0, "checker": 8, "perlin_noise": 250, "noise_tex": 41,
     "image_tex": 10, "throughput_mul": 3, "accumulate": 3,
+    # six rects that close a box as ONE slab test (what the kernel executes): 6 sub + 6 mul for the
+    # plane parameters, 6 min/max per axis pair, 2 + 2 for entry and exit, 3 sub in the range test
+    "box_slab": 25,
 }
-PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+
+
+def fp32_peak_tflops(dev):
+    """Vector FP32 peak of the device in use: CUs x 4 SIMDs x 64 FLOP/clk (16 lanes x FMA x packed
+    v_pk_fma_f32) x the clock the device reports. MI355X: 256 x 4 x 64 x 2.4 GHz = 157.3."""
+    return dev["n_cu"] * 4 * 64 * dev["clock_khz"] * 1e3 / 1e12
+
+
+# The other single-GPU benchmark configurations (kernel time of one render each, same run).
+OTHER_CONFIGS = [
+    ("C1", "final-scene", 200, 200, 10, "tile"),          # (-main :samples 10), core.clj:50-59
+    ("C2", "random-scene", 1200, 800, 500, "tile"),
+    ("C3", "two-perlin-spheres", 1024, 1024, 1000, "tile"),
+    ("C3", "earth", 1024, 1024, 1000, "tile"),
+    ("C3", "simple-light", 1024, 1024, 1000, "tile"),
+    ("C5/1gpu", "final-scene", 3840, 2160, 100, "sample"),  # one GPU's view of the 4K frame, 100 of the 10 000 spp
+]
+
+
+def pmc_record(scene, W, H):
+    """Counters of the profiled launch of this workload (profiles/pmc.json, written by
+    tools/make_pmc_json.py from the rocprofv3 --pmc passes), or {}."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc.json"))).get(f"{scene} {W}x{H}", {})
+    except Exception:
+        return {}
+
+
+def measure_config(ctx, device, scene_name, W, H, spp, peak):
+    """One render of another configuration on this GPU: kernel rate, FLOP by event count, roofline."""
+    cfg, flat = setup(scene_name, scene_seed=1)
+    cam = build_camera(cfg, W / H)
+    sc = ctx.scene(flat)
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    p = abi.make_params(W, H, spp, 50, cfg["background"], seed=0x5EED0001)
+    sc.render_device(cam, abi.make_params(W, H, min(spp, 2), 50, cfg["background"]), acc.data_ptr(), 0, want_stats=True, stream=stream)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    st = sc.render_device(cam, p, acc.data_ptr(), 0, want_stats=True, stream=stream)
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    cp = abi.make_params(W, H, min(spp, 8), 50, cfg["background"], seed=0x5EED0001, flags=abi.RT_FLAG_COUNTERS)
+    cst = sc.render_device(cam, cp, 0, 0, want_stats=True, stream=stream)
+    fps = sum(FLOPS_PER_EVENT[k] * v for k, v in cst["events"].items()) / max(cst["samples"], 1)
+    rv, _ = sc.variants()
+    sc.close()
+    del acc
+    samples = W * H * spp
+    achieved = fps * samples / (st["kernel_ms"] * 1e-3) / 1e12
+    pm = pmc_record(scene_name, W, H)
+    return {"workload": f"{scene_name} {W}x{H} @{spp}spp depth 50", "value": samples / wall / 1e6, "unit": "Msamples/s",
+            "kernel_ms": st["kernel_ms"], "kernel_Msamples_per_s": samples / (st["kernel_ms"] * 1e-3) / 1e6,
+            "rays_per_sample": st["rays"] / samples, "flop_per_sample": fps, "achieved_tflops": achieved,
+            "frac": achieved / peak, "frac_nonpacked": achieved / (peak / 2), "kernel": abi.VARIANT_NAMES[rv],
+            "shader_mhz": st["shader_mhz"], "active_lane_ratio": pm.get("active_lane_ratio")}
 
 
 def cpu_baseline(flat, cam, cfg, seconds=12.0):
@@ -56,10 +114,20 @@ def cpu_baseline(flat, cam, cfg, seconds=12.0):
     t0 = time.perf_counter()
     _, _, rays = ob.render(flat, cam, p, nthreads=threads, want_argb=False)
     dt = time.perf_counter() - t0
-    return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"cornell-box {W}x{H} @{spp}spp depth 50 ({W * H * spp} samples, {dt:.1f} s), "
-                      "C++ FP64 restatement of the Clojure path, not the JVM",
-            "rays_per_sample": rays / (W * H * spp)}
+    out = {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+           "sample": f"cornell-box {W}x{H} @{spp}spp depth 50 ({W * H * spp} samples, {dt:.1f} s), "
+                     "C++ FP64 restatement of the Clojure path, not the JVM",
+           "rays_per_sample": rays / (W * H * spp)}
+    # the reference's own runnable case, (-main :samples 10) = final-scene 200x200 @10 (core.clj:50-59)
+    cfg1, flat1 = setup("final-scene", scene_seed=1)
+    p1 = abi.make_params(200, 200, 10, 50, cfg1["background"], seed=0x5EED0001)
+    t0 = time.perf_counter()
+    ob.render(flat1, build_camera(cfg1, 1.0), p1, nthreads=threads, want_argb=True)
+    dt1 = time.perf_counter() - t0
+    out["main_samples_10"] = {"value": 200 * 200 * 10 / dt1 / 1e6, "unit": "Msamples/s", "seconds": dt1, "cores": threads,
+                              "sample": "final-scene 200x200 @10spp (the whole job), C++ FP64 restatement; JVM unavailable "
+                                        "on this machine, so the Clojure path itself was not timed"}
+    return out
 
 
 def main():
@@ -74,6 +142,7 @@ def main():
     ap.add_argument("--split", default="tile", choices=["tile", "sample"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,12 +174,13 @@ def main():
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device=device)
     argb = torch.zeros((H, W), dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream(device)
-    kernel_ms, rays_total = [], []
+    kernel_ms, rays_total, shader_mhz_seen = [], [], []
 
     def render_fn(p):
         st = scene.render_device(cam, p, acc.data_ptr(), 0, want_stats=True, stream=stream.cuda_stream)
         kernel_ms.append(st["kernel_ms"])
         rays_total.append(st["rays"])
+        shader_mhz_seen.append(st["shader_mhz"])
         return acc
 
     # gloo has no reduce() for device tensors; all_reduce gives rank 0 the same sum
@@ -132,13 +202,14 @@ def main():
     fence()
     kernel_ms.clear()
     rays_total.clear()
+    shader_mhz_seen.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed, float(sum(kernel_ms)) / max(len(kernel_ms), 1), float(sum(rays_total))],
-                     dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, float(sum(kernel_ms)) / max(len(kernel_ms), 1), float(sum(rays_total)),
+                      float(sum(shader_mhz_seen)) / max(len(shader_mhz_seen), 1)], dtype=torch.float64, device=device)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -167,8 +238,12 @@ def main():
         # per-GPU kernel rate: this rank's share of the samples over its own kernel time
         my_samples = samples_per_step / world
         achieved = flop_per_sample * my_samples / (kern_ms_max * 1e-3) / 1e12
+        dev = ctx.device_info()
+        peak = fp32_peak_tflops(dev)
+        shader_mhz = float(t[3]) if world == 1 else None
         traffic = None
         valu_cycles_per_inst = None
+        active_lane_ratio = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         # the profiled launch is the headline workload: its counters say nothing about any other
         headline = (args.scene, W, H, spp) == ("cornell-box", 1024, 1024, 1000)
@@ -180,9 +255,11 @@ def main():
                 # at N = 1): the measured issue cost is 2.7 cycles for FMA-class and 4.5 for
                 # compare/select/min/max/convert/FP64/SGPR-operand instructions, so a value near 3.3
                 # means the VALU issue slots are full
+                active_lane_ratio = prof.get("active_lane_ratio")
                 if world == 1 and prof.get("valu_wave_insts_per_launch"):
-                    props = torch.cuda.get_device_properties(device)
-                    simd_cycles = kern_ms_max * 1e-3 * 2.4e9 * props.multi_processor_count * 4
+                    # real cycles: the shader clock one wave measured during this very kernel
+                    clk = (shader_mhz or dev["clock_khz"] * 1e-3) * 1e6
+                    simd_cycles = kern_ms_max * 1e-3 * clk * dev["n_cu"] * 4
                     valu_cycles_per_inst = simd_cycles / prof["valu_wave_insts_per_launch"]
                 if traffic is not None and world > 1:
                     traffic = traffic / world  # measured at N = 1; a rank writes its own tiles' slots only
@@ -201,14 +278,27 @@ def main():
             "rays_per_sample": rays / (samples_per_step * args.steps),
             "Mrays_per_s": rays / elapsed / 1e6,
             "flop_per_sample": flop_per_sample,
-            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "frac_nonpacked": achieved / (peak / 2),
+                         "peak_nonpacked": peak / 2,
+                         "peak_from": f"{dev['n_cu']} CUs x 4 SIMDs x 64 FLOP/clk x {dev['clock_khz'] / 1e6:.3f} GHz "
+                                      "(device properties); non-packed = half (one v_fma_f32 per lane)",
+                         "shader_mhz_measured": shader_mhz, "active_lane_ratio": active_lane_ratio,
+                         "traffic": traffic,
                          "kernel": "rt::k_render<FEAT, false> (the feature-specialised instantiation this scene selects)", "kernel_ms": kern_ms_max,
                          "simd_cycles_per_valu_instruction": valu_cycles_per_inst,
                          "note": "algorithmic FLOP per event x event counts of the counting build of the same "
                                  "kernel, per GPU, over that GPU's HIP-event kernel time; the path is branchy "
                                  "FP32 VALU work, neither HBM- nor MFMA-bound"},
         }
+        if world == 1 and headline and not args.no_other_configs:
+            scene.close()   # the other worlds take their own slabs (11 GB for the 4K frame)
+            out["other_configs"] = []
+            for tag, name, w2, h2, spp2, split in OTHER_CONFIGS:
+                rec = measure_config(ctx, device, name, w2, h2, spp2, peak)
+                rec["config"] = tag
+                rec["split"] = split
+                out["other_configs"].append(rec)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat, cam, cfg, args.cpu_seconds)
         print(json.dumps(out), flush=True)

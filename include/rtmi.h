@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 1
+#define RTMI_ABI_VERSION 2
 
 enum {
   RT_OK = 0,
@@ -171,6 +171,8 @@ enum {
   RT_EV_LAMBERT, RT_EV_METAL, RT_EV_DIELECTRIC, RT_EV_ISOTROPIC, RT_EV_LIGHT,
   RT_EV_CHECKER, RT_EV_PERLIN_NOISE, RT_EV_NOISE_TEX, RT_EV_IMAGE_TEX,
   RT_EV_THROUGHPUT, RT_EV_ACCUMULATE,
+  RT_EV_BOX_SLAB,     /* six rects that close a box, intersected as one slab test (box.clj:8-24):
+                         what the kernel executes in place of six RT_EV_RECT_TEST               */
   RT_EV_COUNT
 };
 
@@ -179,6 +181,9 @@ typedef struct rt_stats {
   uint64_t rays;                 /* ray-color invocations that reached `hit` (core.clj:23) */
   uint64_t events[RT_EV_COUNT];  /* only with RT_FLAG_COUNTERS, else 0                    */
   double   kernel_ms;            /* HIP-event time of the path kernel alone, on its stream */
+  double   shader_mhz;           /* shader clock DURING the path kernel: one wave reads the cycle
+                                    counter and the constant-rate timer when it starts and when
+                                    it ends; 0 when the device reports no timer rate            */
 } rt_stats;
 
 /* One closest-hit record = the reference's HitRecord (base.clj:169) as `ray-color`
@@ -328,6 +333,16 @@ uint64_t rt_scene_file_size(const rt_scene_desc* desc);
 int rt_scene_write(const rt_scene_desc* desc, void* bytes, uint64_t capacity, uint64_t* written);
 int rt_scene_create_from_memory(rt_ctx* ctx, const void* bytes, uint64_t n_bytes, rt_scene** out);
 int rt_scene_create_from_file(rt_ctx* ctx, const char* path, rt_scene** out);
+
+/* What the context's device reports about itself (hipGetDeviceProperties): the numbers a caller
+ * needs to price a render against the device's peak. */
+typedef struct rt_device_info {
+  int32_t n_cu;              /* compute units                                             */
+  int32_t clock_khz;         /* peak shader clock                                         */
+  int32_t lds_bytes_max;     /* LDS one workgroup may use                                 */
+  int32_t timer_khz;         /* rate of the constant timer rt_stats.shader_mhz is taken against */
+} rt_device_info;
+int rt_get_device_info(const rt_ctx* ctx, rt_device_info* out);
 
 /* Introspection for tests and reports. */
 typedef struct rt_scene_info {

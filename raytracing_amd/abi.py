@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-RTMI_ABI_VERSION = 1
+RTMI_ABI_VERSION = 2
 
 RT_OK, RT_ERR_ARG, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_OOM = 0, -1, -2, -3, -4
 
@@ -26,7 +26,7 @@ RT_EVENT_NAMES = [
     "rect_record", "rotate_y_ray", "rotate_y_rec", "translate_ray", "translate_rec",
     "medium_sample", "camera_ray", "unit_sphere_trial", "unit_disk_trial", "lambert_scatter",
     "metal_scatter", "dielectric_scatter", "iso_scatter", "light_emit", "checker", "perlin_noise",
-    "noise_tex", "image_tex", "throughput_mul", "accumulate",
+    "noise_tex", "image_tex", "throughput_mul", "accumulate", "box_slab",
 ]
 RT_EV_COUNT = len(RT_EVENT_NAMES)
 
@@ -64,7 +64,8 @@ class rt_params(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64),
-                ("events", C.c_uint64 * RT_EV_COUNT), ("kernel_ms", C.c_double)]
+                ("events", C.c_uint64 * RT_EV_COUNT), ("kernel_ms", C.c_double),
+                ("shader_mhz", C.c_double)]
 
 
 class rt_hit(C.Structure):
@@ -82,6 +83,10 @@ class rt_scatter(C.Structure):
 class rt_scene_info(C.Structure):
     _fields_ = [("n_prims_flat", C.c_int32), ("n_groups", C.c_int32), ("n_chains", C.c_int32),
                 ("n_media", C.c_int32), ("n_bvh_nodes", C.c_int32), ("lds_bytes", C.c_int32)]
+
+
+class rt_device_info(C.Structure):
+    _fields_ = [("n_cu", C.c_int32), ("clock_khz", C.c_int32), ("lds_bytes_max", C.c_int32), ("timer_khz", C.c_int32)]
 
 
 def make_camera(cam) -> rt_camera:

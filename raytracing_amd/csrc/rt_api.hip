@@ -66,11 +66,12 @@ struct rt_ctx {
   int device = 0;
   int n_cu = 0;
   int clock_khz = 0;
+  int wall_khz = 0;  // rate of the constant timer (s_memrealtime)
   size_t lds_max = 65536;  // LDS a workgroup may ask for on this device
   unsigned char* scratch = nullptr;  // this device's copy of the file-scope scratch array (rt_render_device_noalloc)
   // reusable device workspace
   uint32_t* d_queue = nullptr;              // the heads of the work-item queue (RT_QUEUE_HEADS lines)
-  unsigned long long* d_stats = nullptr;    // 2 + RT_EV_COUNT words
+  unsigned long long* d_stats = nullptr;    // RT_STATS_WORDS words
   float* d_partial = nullptr;               // n_chunks * W*H*3 partial sums
   size_t partial_bytes = 0;
   void* d_io = nullptr;                     // staging for the host-buffer entry points
@@ -387,11 +388,13 @@ int init_ctx(rt_ctx* ctx) {
   HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
   ctx->n_cu = prop.multiProcessorCount;
   ctx->clock_khz = prop.clockRate;
+  int wall_khz = 0;
+  if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device) == hipSuccess) ctx->wall_khz = wall_khz;
   int lds_max = 0;
   HIPCHK(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device));
   ctx->lds_max = (size_t)lds_max;
   HIPCHK(hipMalloc(&ctx->d_queue, RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4));
-  HIPCHK(hipMalloc(&ctx->d_stats, sizeof(unsigned long long) * (2 + RT_EV_COUNT)));
+  HIPCHK(hipMalloc(&ctx->d_stats, sizeof(unsigned long long) * RT_STATS_WORDS));
   HIPCHK(hipEventCreate(&ctx->ev0));
   HIPCHK(hipEventCreate(&ctx->ev1));
   return RT_OK;
@@ -964,6 +967,15 @@ int rt_scene_get_variants(const rt_scene* sc, int32_t* render_var, uint32_t* cov
   return RT_OK;
 }
 
+int rt_get_device_info(const rt_ctx* ctx, rt_device_info* out) {
+  if (!ctx || !out) return fail(RT_ERR_ARG, "ctx or out is NULL");
+  out->n_cu = ctx->n_cu;
+  out->clock_khz = ctx->clock_khz;
+  out->lds_bytes_max = (int32_t)ctx->lds_max;
+  out->timer_khz = ctx->wall_khz;
+  return RT_OK;
+}
+
 int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
   if (!sc || !out) return fail(RT_ERR_ARG, "scene or out is NULL");
   *out = sc->info;
@@ -978,7 +990,7 @@ static int render_enqueue(rt_ctx* ctx, const rt_scene* sc, const DRender& R, con
                           unsigned long long* d_stats, float* partial, float* d_rgb_sum, uint32_t* d_argb,
                           rt_stats* stats, hipStream_t stream) {
   HIPCHK(hipMemsetAsync(queue, 0, RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4, stream));
-  HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * (2 + RT_EV_COUNT), stream));
+  HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * RT_STATS_WORDS, stream));
   // persistent grid: as many workgroups as stay resident, never more than there is work for
   int grid = ctx->n_cu * sc->blocks_per_cu[count ? 1 : 0];
   int grid_needed = (R.n_items + RT_BLOCK - 1) / RT_BLOCK;
@@ -989,7 +1001,7 @@ static int render_enqueue(rt_ctx* ctx, const rt_scene* sc, const DRender& R, con
   if (stats) HIPCHK(hipEventRecord(ctx->ev1, stream));
   if (d_rgb_sum || d_argb) HIPCHK(launch_resolve(R, partial, d_rgb_sum, d_argb, stream));
   if (stats) {
-    unsigned long long h[2 + RT_EV_COUNT];
+    unsigned long long h[RT_STATS_WORDS];
     HIPCHK(hipMemcpyAsync(h, d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     float ms = 0.f;
@@ -999,6 +1011,9 @@ static int render_enqueue(rt_ctx* ctx, const rt_scene* sc, const DRender& R, con
     stats->rays = h[1];
     for (int e = 0; e < RT_EV_COUNT; ++e) stats->events[e] = h[2 + e];
     stats->kernel_ms = ms;
+    // cycle counter over constant-rate timer, both read by one wave at its start and at its end
+    const unsigned long long cyc = h[RT_STATS_CLOCK + 1] - h[RT_STATS_CLOCK], tim = h[RT_STATS_CLOCK + 3] - h[RT_STATS_CLOCK + 2];
+    if (R.n_items > 0 && tim > 0 && ctx->wall_khz > 0) stats->shader_mhz = (double)cyc / (double)tim * ctx->wall_khz * 1e-3;
   }
   return RT_OK;
 }
@@ -1034,10 +1049,10 @@ static int render_device_impl(rt_ctx* ctx, const rt_scene* sc, const rt_camera* 
 // rt_init and kept in the context); every call on a GPU shares that GPU's copy.
 #define RT_SCRATCH_BYTES (32u << 20)
 #define RT_SCRATCH_QUEUE_OFF 0u       // RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4 = 1024 bytes
-#define RT_SCRATCH_STATS_OFF 1024u    // (2 + RT_EV_COUNT) * 8 bytes
+#define RT_SCRATCH_STATS_OFF 1024u    // RT_STATS_WORDS * 8 bytes
 #define RT_SCRATCH_SLAB_OFF 4096u
 static_assert(RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4 <= RT_SCRATCH_STATS_OFF, "queue heads overlap the counters");
-static_assert(RT_SCRATCH_STATS_OFF + (2 + RT_EV_COUNT) * 8 <= RT_SCRATCH_SLAB_OFF, "counters overlap the slab");
+static_assert(RT_SCRATCH_STATS_OFF + RT_STATS_WORDS * 8 <= RT_SCRATCH_SLAB_OFF, "counters overlap the slab");
 static __device__ __align__(256) unsigned char scratch[RT_SCRATCH_BYTES];
 
 // Called by rt_init with the context's device current.

@@ -672,7 +672,7 @@ RT_DEV void brute_boxes(const float RT_CONST* B, int n_box, const RayX& r, float
     // the whole record in SGPRs before any of it is used: one scalar-memory round trip per box
     asm volatile("" ::"s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]), "s"(w[4]), "s"(w[5]), "s"(w[6]), "s"(w[7]), "s"(w[8]),
                  "s"(w[9]), "s"(w[10]), "s"(w[11]));
-    tally.template add<RT_EV_RECT_TEST>(6);
+    tally.template add<RT_EV_BOX_SLAB>();
     const BoxSlab s = box_slab(w, r);
     float t;
     const bool ok = box_accept(s, tmin, best.t, t);
@@ -918,7 +918,7 @@ RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax,
       float w[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) w[q] = B[q];
-      tally.template add<RT_EV_RECT_TEST>(12);
+      tally.template add<RT_EV_BOX_SLAB>();
       const BoxSlab s = box_slab(w, r);
       if (!box_accept(s, -INF, INF, b1.t)) return false;
       if (!box_accept(s, after_t(b1.t), INF, b2.t)) return false;

@@ -214,7 +214,12 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
   unsigned long long* __restrict__ stats = A.stats;
   Tally<COUNT> tally;
   if constexpr (COUNT) tally.clear();
-
+  // the shader clock during this kernel: one wave notes the cycle counter and the constant-rate timer
+  const bool clock_wave = blockIdx.x == 0 && threadIdx.x == 0;
+  if (clock_wave) {
+    stats[RT_STATS_CLOCK + 0] = __builtin_readcyclecounter();
+    stats[RT_STATS_CLOCK + 2] = __builtin_amdgcn_s_memrealtime();
+  }
 
   // wave-uniform queue window [q_next, q_end) of work items taken from the global queue
   uint32_t q_next = 0, q_end = 0;
@@ -422,6 +427,10 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
 #endif
   }
   const uint32_t lane = wave_lane();
+  if (clock_wave) {
+    stats[RT_STATS_CLOCK + 1] = __builtin_readcyclecounter();
+    stats[RT_STATS_CLOCK + 3] = __builtin_amdgcn_s_memrealtime();
+  }
 #ifdef RT_STAMPS
   if (lane == 0) {
     atomicAdd(&stats[2 + 0], c_queue); atomicAdd(&stats[2 + 1], c_cam); atomicAdd(&stats[2 + 2], c_hit);

@@ -16,6 +16,8 @@
 
 #include <stdint.h>
 
+#include "../../include/rtmi.h"
+
 #define RT_MAX_CHAIN_OPS 4     // deepest Translate/RotateY nesting supported
 #define RT_BRUTE_MAX 16        // groups up to this size skip the BVH
 #define RT_MAX_PERLIN_LDS 8    // Perlin table sets staged in LDS
@@ -29,6 +31,11 @@
 #define RT_PAIR_BATCH 2        // pair records the rect kernels' brute-force loop fetches per scalar-memory round trip (1 to 4)
 #endif
 #define RT_PAIR_SLACK 4        // records of slack after the table: the most a batch reads past its end
+
+// The statistics buffer of a render: samples, rays, the event counters, then four clock words
+// (cycle counter at the start and end of one wave, constant-rate timer at the same two moments).
+#define RT_STATS_CLOCK (2 + RT_EV_COUNT)
+#define RT_STATS_WORDS (2 + RT_EV_COUNT + 4)
 
 enum { DOP_TRANSLATE = 0, DOP_ROTATE_Y = 1 };
 

@@ -17,7 +17,7 @@ EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version", "rt_scen
            "rt_tonemap_device", "rt_hit_batch", "rt_sample_batch", "rt_scene_file_size",
            "rt_scene_write", "rt_scene_create_from_memory", "rt_scene_create_from_file",
            "rt_scene_create_with", "rt_scene_get_variants", "rt_hit_batch_variant", "rt_scatter_batch",
-           "rt_render_device_noalloc"]
+           "rt_render_device_noalloc", "rt_get_device_info"]
 
 _LIB = None
 
@@ -59,6 +59,7 @@ def load():
     L.rt_scatter_batch.argtypes = [vp, vp, C.c_uint64, C.c_int32, fp, fp, fp, ip, ip, ip, C.POINTER(abi.rt_scatter)]
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_scene_destroy.restype = None
+    L.rt_get_device_info.argtypes = [vp, C.POINTER(abi.rt_device_info)]
     L.rt_scene_get_info.argtypes = [vp, C.POINTER(abi.rt_scene_info)]
     L.rt_render.argtypes = [vp, vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), fp, u32p,
                             C.POINTER(abi.rt_stats)]
@@ -101,7 +102,7 @@ def scene_file_bytes(flat) -> bytes:
 
 
 def stats_dict(st: abi.rt_stats) -> dict:
-    return dict(samples=int(st.samples), rays=int(st.rays), kernel_ms=float(st.kernel_ms),
+    return dict(samples=int(st.samples), rays=int(st.rays), kernel_ms=float(st.kernel_ms), shader_mhz=float(st.shader_mhz),
                 events={n: int(st.events[i]) for i, n in enumerate(abi.RT_EVENT_NAMES)})
 
 
@@ -124,6 +125,11 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def device_info(self) -> dict:
+        out = abi.rt_device_info()
+        _check(self._L.rt_get_device_info(self._h, C.byref(out)))
+        return {n: getattr(out, n) for n, _ in abi.rt_device_info._fields_}
 
     def scene(self, flat, bvh_builder: int = abi.RT_BVH_DEFAULT) -> "Scene":
         return Scene(self, flat, bvh_builder=bvh_builder)
