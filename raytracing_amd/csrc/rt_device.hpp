@@ -689,6 +689,32 @@ RT_DEV void brute_boxes(const float RT_CONST* B, int n_box, const RayX& r, float
   }
 }
 
+// The brute-force loops of group G (rect pairs, closed boxes, spheres in scan order) for the
+// group-space ray r.
+template <class X, class T>
+RT_DEV void brute_group_hit(const DScene& S, const DGroup RT_CONST& G, const RayX& r, float tmin, Best& best, T& tally,
+                            double tmin64) {
+  const DPrim RT_CONST* prims = cptr(S.prims);
+  int first = G.first_prim;
+  const int loose = G.loose;
+  brute_rects<pair_batch<X>()>(cptr(S.brute_rects) + G.first_rect * RT_PAIR_STRIDE, loose & 255, (loose >> 8) & 255, (loose >> 16) & 255,
+              r, tmin, best, tally);
+  brute_boxes(cptr(S.brute_boxes) + G.first_box * RT_BOX_STRIDE, loose >> 24, r, tmin, best, tally);
+  first += G.n_xy + G.n_xz + G.n_yz;
+  if constexpr (X::has(F_SPHERES)) {
+    const int n_sph = G.n_sph;
+    for (int i = 0; i < n_sph; ++i) {
+      const DPrim RT_CONST& P = prims[first + i];
+      float t = 0.f;
+      double root = 0.0;
+      bool ok = sphere_t<sphere_mode<X>()>(P, prim_type(P.type), r, tmin64, best.t, t, root, tally);
+      best.t = ok ? t : best.t;
+      best.prim = ok ? first + i : best.prim;
+      best.root = ok ? root : best.root;
+    }
+  }
+}
+
 // Closest hit of group g for the world ray wr with t in (tmin, best.t].
 // tmin64: the lower bound the spheres compare their FP64 roots with (the FP32 bound widened, unless
 // the caller holds a more exact one).
@@ -701,25 +727,7 @@ RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best
   if (X::has(F_BVH) && bvh_root >= 0) {
     if constexpr (X::has(F_BVH)) bvh_traverse(ctx, bvh_root, r, tmin, best, tally, tmin64);
   } else {
-    const DPrim RT_CONST* prims = cptr(S.prims);
-    int first = G.first_prim;
-    const int loose = G.loose;
-    brute_rects<pair_batch<X>()>(cptr(S.brute_rects) + G.first_rect * RT_PAIR_STRIDE, loose & 255, (loose >> 8) & 255, (loose >> 16) & 255,
-                r, tmin, best, tally);
-    brute_boxes(cptr(S.brute_boxes) + G.first_box * RT_BOX_STRIDE, loose >> 24, r, tmin, best, tally);
-    first += G.n_xy + G.n_xz + G.n_yz;
-    if constexpr (X::has(F_SPHERES)) {
-      const int n_sph = G.n_sph;
-      for (int i = 0; i < n_sph; ++i) {
-        const DPrim RT_CONST& P = prims[first + i];
-        float t = 0.f;
-        double root = 0.0;
-        bool ok = sphere_t<sphere_mode<X>()>(P, prim_type(P.type), r, tmin64, best.t, t, root, tally);
-        best.t = ok ? t : best.t;
-        best.prim = ok ? first + i : best.prim;
-        best.root = ok ? root : best.root;
-      }
-    }
+    brute_group_hit<X>(S, G, r, tmin, best, tally, tmin64);
   }
 }
 
@@ -960,34 +968,31 @@ RT_DEV bool medium_t(const X& ctx, int m, const Ray& wr, float tmin, float tmax,
 // (hit (->HittableList world) r t-min t-max {}) of core.clj:23 over the flattened world.
 // medium_xi: scripted uniforms per medium (parity hook) or nullptr to draw from `g`;
 // skip_media drops MEDIUM nodes altogether.
+// The constant media of the world against the closest surface hit so far (constant_medium.clj:11-44
+// for each, in medium order).
 template <class X, class T>
-RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, const Rng& g, uint32_t bounce,
-                        const float* medium_xi, bool skip_media, bool want_uv_always, Rec& rec, T& tally,
-                        unsigned long long* g_stamp_inner = nullptr) {
-  const DScene& S = ctx.S;
-  Best best{tmax, -1, 0.0};
-  const int n_surface = S.n_surface_groups;
-  for (int gi = 0; gi < n_surface; ++gi) group_hit(ctx, gi, wr, tmin, best, tally, (double)tmin);
-#ifdef RT_STAMPS
-  if (g_stamp_inner) { __builtin_amdgcn_sched_barrier(0); *g_stamp_inner = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-#endif
+RT_DEV void media_hit(const X& ctx, const Ray& wr, float tmin, const Rng& g, uint32_t bounce, const float* medium_xi,
+                      Best& best, T& tally) {
   if constexpr (X::has(F_MEDIA)) {
-    if (!skip_media) {
-      const int n_media = S.n_media;
-      // one block of the keyed stream serves four media: drawn here for every lane, once, instead
-      // of inside each medium for the lanes that cross it
-      uint32_t block[4] = {0u, 0u, 0u, 0u};
-      for (int m = 0; m < n_media; ++m) {
-        if (medium_xi == nullptr && (m & 3) == 0) philox(g, (uint32_t)m >> 2, bounce, P_MEDIUM, block);
-        float tm;
-        if (medium_t(ctx, m, wr, tmin, best.t, medium_xi ? medium_xi[m] : 0.f, medium_xi != nullptr, block,
-                     tm, tally)) {
-          best.t = tm; best.prim = -2 - m;
-        }
+    const int n_media = ctx.S.n_media;
+    // one block of the keyed stream serves four media: drawn here for every lane, once, instead
+    // of inside each medium for the lanes that cross it
+    uint32_t block[4] = {0u, 0u, 0u, 0u};
+    for (int m = 0; m < n_media; ++m) {
+      if (medium_xi == nullptr && (m & 3) == 0) philox(g, (uint32_t)m >> 2, bounce, P_MEDIUM, block);
+      float tm;
+      if (medium_t(ctx, m, wr, tmin, best.t, medium_xi ? medium_xi[m] : 0.f, medium_xi != nullptr, block,
+                   tm, tally)) {
+        best.t = tm; best.prim = -2 - m;
       }
     }
   }
-  if (best.prim == -1) return false;
+}
+
+// The HitRecord of the winner `best` (best.prim != -1) for the world ray wr.
+template <class X, class T>
+RT_DEV void hit_record(const X& ctx, const Ray& wr, const Best& best, bool want_uv_always, Rec& rec, T& tally) {
+  const DScene& S = ctx.S;
   if (!X::has(F_MEDIA) || best.prim >= 0) {
     const int prim = best.prim;
     const DPrimInfo I = load_info(ctx, prim);
@@ -1016,6 +1021,22 @@ RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, con
       chain_unwind(ctx, outer, wr.d, rec, tally);
     }
   }
+}
+
+template <class X, class T>
+RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, const Rng& g, uint32_t bounce,
+                        const float* medium_xi, bool skip_media, bool want_uv_always, Rec& rec, T& tally,
+                        unsigned long long* g_stamp_inner = nullptr) {
+  const DScene& S = ctx.S;
+  Best best{tmax, -1, 0.0};
+  const int n_surface = S.n_surface_groups;
+  for (int gi = 0; gi < n_surface; ++gi) group_hit(ctx, gi, wr, tmin, best, tally, (double)tmin);
+#ifdef RT_STAMPS
+  if (g_stamp_inner) { __builtin_amdgcn_sched_barrier(0); *g_stamp_inner = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#endif
+  if (!skip_media) media_hit(ctx, wr, tmin, g, bounce, medium_xi, best, tally);
+  if (best.prim == -1) return false;
+  hit_record(ctx, wr, best, want_uv_always, rec, tally);
   return true;
 }
 
