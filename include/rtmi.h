@@ -158,8 +158,12 @@ typedef struct rt_params {
 } rt_params;
 
 enum {
-  RT_FLAG_COUNTERS = 1    /* run the event-counting build of the path kernel and fill
+  RT_FLAG_COUNTERS = 1,   /* run the event-counting build of the path kernel and fill
                              rt_stats.events (slower; never use its timing)               */
+  RT_FLAG_LANE_PATHS = 2  /* worlds with trees: render on the kernel in which a lane owns a path
+                             from camera ray to termination instead of the one that re-packs
+                             paths between the stages of a bounce. Same frame, bit for bit;
+                             slower; kept for comparison                                   */
 };
 
 /* Event counters, indexed by RT_EV_*; the unit costs live next to the enum. */

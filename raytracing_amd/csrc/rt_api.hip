@@ -88,6 +88,8 @@ struct rt_scene {
   bool has_time_bounds = false;
   float time_lo = 0.f, time_hi = 1.f;
   int blocks_per_cu[2] = {0, 0};  // occupancy of k_render<false>, k_render<true>
+  bool pool = false;              // the world renders on k_render_pool unless the caller asks otherwise
+  int pool_blocks_per_cu[2] = {0, 0};
   int n_shadowed_spheres = 0;     // duplicates left out of their groups' tested ranges (exact for t-min >= 0)
 };
 
@@ -897,6 +899,17 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
     S.nodes = static_cast<const DBvhNode16*>(p);
   }
   S.bvh_stack = n_bvh_nodes ? max_height + 1 : 0;
+  S.n_bvh_nodes = n_bvh_nodes;
+  {
+    std::vector<int32_t> bvh_next(groups.size(), -1);
+    int next = -1;
+    for (int gi = n_surface_groups - 1; gi >= 0; --gi) {
+      bvh_next[(size_t)gi] = next;
+      if (groups[(size_t)gi].bvh_root >= 0) next = gi;
+    }
+    S.first_bvh_group = next;
+    if ((rc = upload(sc, bvh_next, &S.bvh_next))) return rc;
+  }
   if (n_bvh_nodes) features |= F_BVH;
   if (d->n_media) features |= F_MEDIA;
   if (chain_recs.size() > 1) features |= F_CHAINS;
@@ -933,9 +946,17 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
     return fail(RT_ERR_UNSUPPORTED, "scene needs %zu bytes of LDS per workgroup (BVH height %d); this device allows %zu",
                 lds_any, max_height, ctx->lds_max);
   HIPCHK(allow_lds(lds_any));
-  HIPCHK(render_occupancy(S, false, &sc->blocks_per_cu[0]));
-  HIPCHK(render_occupancy(S, true, &sc->blocks_per_cu[1]));
+  HIPCHK(render_occupancy(S, false, false, &sc->blocks_per_cu[0]));
+  HIPCHK(render_occupancy(S, true, false, &sc->blocks_per_cu[1]));
   if (sc->blocks_per_cu[0] < 1 || sc->blocks_per_cu[1] < 1) return fail(RT_ERR_HIP, "path kernel does not fit a compute unit");
+  // worlds with trees render on the kernel that re-packs paths between the stages of a bounce
+  sc->pool = pool_kernel_covers(S) && pool_lds_bytes(S, RT_BLOCK) <= ctx->lds_max;
+  if (sc->pool) {
+    HIPCHK(allow_lds(std::max(lds_any, pool_lds_bytes(S, RT_BLOCK))));
+    HIPCHK(render_occupancy(S, false, true, &sc->pool_blocks_per_cu[0]));
+    HIPCHK(render_occupancy(S, true, true, &sc->pool_blocks_per_cu[1]));
+    if (sc->pool_blocks_per_cu[0] < 1 || sc->pool_blocks_per_cu[1] < 1) sc->pool = false;
+  }
 
   sc->info.n_prims_flat = (int)prims.size();
   sc->info.n_groups = (int)groups.size();
@@ -986,18 +1007,19 @@ int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
 // the persistent grid, resolves the partial sums. `queue`, `d_stats` and `partial` are the scratch
 // buffers of this render (the context's own, or the file-scope array of the entry point that
 // allocates nothing). Synchronises only when `stats` is asked for.
-static int render_enqueue(rt_ctx* ctx, const rt_scene* sc, const DRender& R, const DCamera& C, bool count, uint32_t* queue,
+static int render_enqueue(rt_ctx* ctx, const rt_scene* sc, const DRender& R, const DCamera& C, bool count, bool pool, uint32_t* queue,
                           unsigned long long* d_stats, float* partial, float* d_rgb_sum, uint32_t* d_argb,
                           rt_stats* stats, hipStream_t stream) {
   HIPCHK(hipMemsetAsync(queue, 0, RT_QUEUE_HEADS * RT_QUEUE_STRIDE * 4, stream));
   HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * RT_STATS_WORDS, stream));
   // persistent grid: as many workgroups as stay resident, never more than there is work for
-  int grid = ctx->n_cu * sc->blocks_per_cu[count ? 1 : 0];
+  const int per_cu = pool ? sc->pool_blocks_per_cu[count ? 1 : 0] : sc->blocks_per_cu[count ? 1 : 0];
+  int grid = ctx->n_cu * per_cu;
   int grid_needed = (R.n_items + RT_BLOCK - 1) / RT_BLOCK;
   grid = std::max(1, std::min(grid, grid_needed));
   if (stats) HIPCHK(hipEventRecord(ctx->ev0, stream));
   if (R.n_items > 0)
-    HIPCHK(launch_render(sc->S, C, R, partial, queue, d_stats, count, grid, stream));
+    HIPCHK(launch_render(sc->S, C, R, partial, queue, d_stats, count, pool, grid, stream));
   if (stats) HIPCHK(hipEventRecord(ctx->ev1, stream));
   if (d_rgb_sum || d_argb) HIPCHK(launch_resolve(R, partial, d_rgb_sum, d_argb, stream));
   if (stats) {
@@ -1039,7 +1061,7 @@ static int render_device_impl(rt_ctx* ctx, const rt_scene* sc, const rt_camera* 
     HIPCHK(hipMalloc(&ctx->d_partial, need));
     ctx->partial_bytes = need;
   }
-  return render_enqueue(ctx, sc, R, C, count, ctx->d_queue, ctx->d_stats, ctx->d_partial, d_rgb_sum, d_argb, stats, stream);
+  return render_enqueue(ctx, sc, R, C, count, sc->pool && !(p->flags & RT_FLAG_LANE_PATHS), ctx->d_queue, ctx->d_stats, ctx->d_partial, d_rgb_sum, d_argb, stats, stream);
 }
 
 // ---- the entry point that allocates nothing ------------------------------------------------
@@ -1082,7 +1104,7 @@ int rt_render_device_noalloc(rt_ctx* ctx, const rt_scene* sc, const rt_camera* c
   DCamera C;
   fill_camera(cam, p, C);
   unsigned char* base = ctx->scratch;
-  return render_enqueue(ctx, sc, R, C, false, reinterpret_cast<uint32_t*>(base + RT_SCRATCH_QUEUE_OFF),
+  return render_enqueue(ctx, sc, R, C, false, sc->pool && !(p->flags & RT_FLAG_LANE_PATHS), reinterpret_cast<uint32_t*>(base + RT_SCRATCH_QUEUE_OFF),
                         reinterpret_cast<unsigned long long*>(base + RT_SCRATCH_STATS_OFF),
                         reinterpret_cast<float*>(base + RT_SCRATCH_SLAB_OFF), d_rgb_sum, d_argb, nullptr,
                         static_cast<hipStream_t>(hip_stream));

@@ -1172,35 +1172,38 @@ RT_DEV bool needs_sphere_draw(int mtype) {
 }
 // With PRE, `sv` is random-in-unit-sphere for this bounce, drawn by the caller when
 // needs_sphere_draw(mtype); without it the material draws its own.
+// The branches only produce the scattered DIRECTION; the one assignment of the scattered ray (origin
+// = the hit point, time kept) follows them. (With the origin assigned inside every branch the
+// compiler kept it in a register that the dielectric branch's random draw reused: reflected glass
+// bounces came out with a garbage origin in one kernel instantiation.)
 template <bool PRE, class X, class T>
 RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t bounce, V3 sv, V3& attenuation,
                     V3& emitted, T& tally) {
   const int type = rec.mtype, flags = rec.mflags, tex = rec.mtex;
   const V3 rgb = rec.rgb;
   emitted = mk(0.f, 0.f, 0.f);
+  attenuation = mk(0.f, 0.f, 0.f);
+  V3 dir = r.d;
+  bool ok = false;
   if (type == RT_MAT_LAMBERTIAN) {  // :16-23
     tally.template add<RT_EV_LAMBERT>();
-    V3 dir = rec.n + unit(PRE ? sv : random_in_unit_sphere(g, bounce, tally));  // random-unit-vector, base.clj:196-197
+    dir = rec.n + unit(PRE ? sv : random_in_unit_sphere(g, bounce, tally));  // random-unit-vector, base.clj:196-197
     attenuation = material_colour(ctx, flags, tex, rgb, rec, tally);
-    r.o = rec.p; r.d = dir;
-    return true;
-  }
-  if (type == RT_MAT_DIFFUSE_LIGHT) {  // :69-78 (the unused scatter direction is not drawn)
+    ok = true;
+  } else if (type == RT_MAT_DIFFUSE_LIGHT) {  // :69-78 (the unused scatter direction is not drawn)
     tally.template add<RT_EV_LIGHT>();
     emitted = material_colour(ctx, flags, tex, rgb, rec, tally);
     attenuation = emitted;
-    return false;
-  }
-  if constexpr (X::has(F_SPECULAR)) {
-    if (type == RT_MAT_METAL) {  // :33-39
+  } else if (X::has(F_SPECULAR) && type == RT_MAT_METAL) {  // :33-39
+    if constexpr (X::has(F_SPECULAR)) {
       tally.template add<RT_EV_METAL>();
       V3 reflected = reflect(unit(r.d), rec.n);
-      V3 dir = madd(PRE ? sv : random_in_unit_sphere(g, bounce, tally), rec.mx, reflected);
+      dir = madd(PRE ? sv : random_in_unit_sphere(g, bounce, tally), rec.mx, reflected);
       attenuation = rgb;
-      r.o = rec.p; r.d = dir;
-      return dot(dir, rec.n) > 0.0f;
+      ok = dot(dir, rec.n) > 0.0f;
     }
-    if (type == RT_MAT_DIELECTRIC) {  // :47-61
+  } else if (X::has(F_SPECULAR) && type == RT_MAT_DIELECTRIC) {  // :47-61
+    if constexpr (X::has(F_SPECULAR)) {
       tally.template add<RT_EV_DIELECTRIC>();
       float ir = rec.rgb.x;
       float ratio = rec.front ? (1.0f / ir) : ir;
@@ -1213,23 +1216,22 @@ RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t
         philox(g, 0, bounce, P_DIEL, o4);
         reflect_it = reflectance(cos_theta, ratio) > u24(o4[0]);
       }
-      V3 dir = reflect_it ? reflect(ud, rec.n) : refract(ud, rec.n, ratio);
+      dir = reflect_it ? reflect(ud, rec.n) : refract(ud, rec.n, ratio);
       attenuation = mk(1.f, 1.f, 1.f);
-      r.o = rec.p; r.d = dir;
-      return true;
+      ok = true;
     }
-  }
-  if constexpr (X::has(F_MEDIA)) {
-    if (type == RT_MAT_ISOTROPIC) {  // :87-90 — direction not normalised
+  } else if (X::has(F_MEDIA) && type == RT_MAT_ISOTROPIC) {  // :87-90 — direction not normalised
+    if constexpr (X::has(F_MEDIA)) {
       tally.template add<RT_EV_ISOTROPIC>();
-      V3 dir = PRE ? sv : random_in_unit_sphere(g, bounce, tally);
+      dir = PRE ? sv : random_in_unit_sphere(g, bounce, tally);
       attenuation = material_colour(ctx, flags, tex, rgb, rec, tally);
-      r.o = rec.p; r.d = dir;
-      return true;
+      ok = true;
     }
   }
-  attenuation = mk(0.f, 0.f, 0.f);  // unreachable: the host picks an instantiation that covers the scene
-  return false;
+  // (any other type: the host picks an instantiation that covers the scene)
+  r.o = rec.p;   // the scattered ray starts at the hit point; a caller only reads it when ok
+  r.d = dir;
+  return ok;
 }
 
 // --------------------------------------------------------------------------------- camera

@@ -616,6 +616,28 @@ size_t variant_lds_bytes(const DScene& S, int block, int variant) {
 }
 size_t shade_lds_bytes(const DScene& S, int block) { return variant_lds_bytes(S, block, pick_variant(S)); }
 
+}  // namespace rt
+#include "rt_pool.hpp"
+namespace rt {
+
+// k_render_pool exists for the two instantiations worlds with trees select; its 16-bit stack entries
+// and 8-bit stack depths bound the trees it takes.
+bool pool_kernel_covers(const DScene& S) {
+  const int v = pick_variant(S);
+  return (v == 2 || v == 4) && S.first_bvh_group >= 0 && S.n_bvh_nodes < 32768 && S.n_prims < 32768 &&
+         S.bvh_stack < 256 && S.n_groups < (1 << 23);
+}
+size_t pool_lds_bytes(const DScene& S, int block) {
+  const size_t vec_bytes = (size_t)S.n_perlin * 4096;
+  const size_t perm_bytes = ((size_t)S.n_perlin * 768 + 15) & ~(size_t)15;
+  return vec_bytes + perm_bytes + (size_t)(block / 64) * 1024 + (size_t)(block / 64) * pool_wave_bytes(S.bvh_stack);
+}
+template <class F>
+auto with_pool_kernel(const DScene& S, bool count, F&& f) {
+  if (pick_variant(S) == 2) return count ? f(k_render_pool<V_SPH, true>) : f(k_render_pool<V_SPH, false>);
+  return count ? f(k_render_pool<V_ALL, true>) : f(k_render_pool<V_ALL_DEEP, false>);
+}
+
 template <class F>
 auto with_render_kernel(const DScene& S, bool count, F&& f) {
   switch (pick_variant(S) * 2 + (count ? 1 : 0)) {
@@ -645,11 +667,22 @@ hipError_t allow_lds(size_t bytes) {
   RT_ALLOW(V_RECT) RT_ALLOW(V_SMOKE) RT_ALLOW(V_SPH) RT_ALLOW(V_ALL) RT_ALLOW(V_FULL)
 #undef RT_ALLOW
   allow(k_render<V_ALL_DEEP, false>); allow(k_hit_batch<V_ALL_DEEP>);
+  allow(k_render_pool<V_SPH, false>); allow(k_render_pool<V_SPH, true>);
+  allow(k_render_pool<V_ALL_DEEP, false>); allow(k_render_pool<V_ALL, true>);
   return e;
 }
 
 hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, float* out, uint32_t* queue,
-                         unsigned long long* stats, bool count, int grid, hipStream_t stream) {
+                         unsigned long long* stats, bool count, bool pool, int grid, hipStream_t stream) {
+  if (pool) {
+    const size_t lds = pool_lds_bytes(S, RT_BLOCK);
+    return with_pool_kernel(S, count, [&](auto kernel) {
+      RenderArgs A;
+      A.S = S; A.cam = cam; A.R = R; A.out = out; A.queue = queue; A.stats = stats;
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(RT_BLOCK), lds, stream, A);
+      return hipGetLastError();
+    });
+  }
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
   return with_render_kernel(S, count, [&](auto kernel) {
     RenderArgs A;
@@ -659,7 +692,13 @@ hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, 
   });
 }
 
-hipError_t render_occupancy(const DScene& S, bool count, int* blocks_per_cu) {
+hipError_t render_occupancy(const DScene& S, bool count, bool pool, int* blocks_per_cu) {
+  if (pool) {
+    const size_t lds = pool_lds_bytes(S, RT_BLOCK);
+    return with_pool_kernel(S, count, [&](auto kernel) {
+      return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, RT_BLOCK, lds);
+    });
+  }
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
   return with_render_kernel(S, count, [&](auto kernel) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, RT_BLOCK, lds);

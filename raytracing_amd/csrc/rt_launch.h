@@ -16,8 +16,11 @@ size_t shade_lds_bytes(const DScene& S, int block);
 // 64 KiB every kernel may use without asking; the device allows 160 KiB).
 hipError_t allow_lds(size_t bytes);
 hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, float* out, uint32_t* queue,
-                         unsigned long long* stats, bool count, int grid, hipStream_t stream);
-hipError_t render_occupancy(const DScene& S, bool count, int* blocks_per_cu);
+                         unsigned long long* stats, bool count, bool pool, int grid, hipStream_t stream);
+hipError_t render_occupancy(const DScene& S, bool count, bool pool, int* blocks_per_cu);
+// k_render_pool: the path loop that re-packs paths between stages (worlds with trees).
+bool pool_kernel_covers(const DScene& S);
+size_t pool_lds_bytes(const DScene& S, int block);
 hipError_t launch_resolve(const DRender& R, const float* partial, float* rgb_sum, uint32_t* argb,
                           hipStream_t stream);
 hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t* argb, hipStream_t stream);

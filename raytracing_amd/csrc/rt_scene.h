@@ -219,6 +219,9 @@ struct DScene {
   int32_t n_media;
   int32_t n_perlin;
   int32_t bvh_stack;             // entries per lane the traversal stack needs (0 = no BVH)
+  const int32_t* bvh_next;       // per group: the next surface group after it that has a tree, or -1
+  int32_t first_bvh_group;       // the first surface group with a tree, or -1
+  int32_t n_bvh_nodes;
   uint32_t features;             // F_* mask of what this scene needs from a kernel instantiation
 };
 
