@@ -160,10 +160,15 @@ typedef struct rt_params {
 enum {
   RT_FLAG_COUNTERS = 1,   /* run the event-counting build of the path kernel and fill
                              rt_stats.events (slower; never use its timing)               */
-  RT_FLAG_LANE_PATHS = 2  /* worlds with trees: render on the kernel in which a lane owns a path
-                             from camera ray to termination instead of the one that re-packs
-                             paths between the stages of a bounce. Same frame, bit for bit;
-                             slower; kept for comparison                                   */
+  RT_FLAG_POOL_PATHS = 2  /* worlds with trees: render on the kernel that keeps a pool of paths per
+                             wave in LDS and re-packs them onto the lanes between the stages of a
+                             bounce (camera ray, brute-force groups, tree walk, leaf tests,
+                             record + scatter) instead of the one in which a lane owns a path from
+                             camera ray to termination. Same frame, bit for bit. Its stages run
+                             with 85-95 % of the lanes busy (34 % in the default kernel), but the
+                             pool's LDS leaves room for two waves per SIMD and the tree walk then
+                             waits on its node fetches: it is 2.5 x slower today. Ignored for
+                             worlds without trees.                                            */
 };
 
 /* Event counters, indexed by RT_EV_*; the unit costs live next to the enum. */

@@ -88,7 +88,7 @@ struct rt_scene {
   bool has_time_bounds = false;
   float time_lo = 0.f, time_hi = 1.f;
   int blocks_per_cu[2] = {0, 0};  // occupancy of k_render<false>, k_render<true>
-  bool pool = false;              // the world renders on k_render_pool unless the caller asks otherwise
+  bool pool = false;              // the world can render on k_render_pool (RT_FLAG_POOL_PATHS)
   int pool_blocks_per_cu[2] = {0, 0};
   int n_shadowed_spheres = 0;     // duplicates left out of their groups' tested ranges (exact for t-min >= 0)
 };
@@ -949,7 +949,7 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
   HIPCHK(render_occupancy(S, false, false, &sc->blocks_per_cu[0]));
   HIPCHK(render_occupancy(S, true, false, &sc->blocks_per_cu[1]));
   if (sc->blocks_per_cu[0] < 1 || sc->blocks_per_cu[1] < 1) return fail(RT_ERR_HIP, "path kernel does not fit a compute unit");
-  // worlds with trees render on the kernel that re-packs paths between the stages of a bounce
+  // worlds with trees can render on the kernel that re-packs paths between the stages of a bounce (RT_FLAG_POOL_PATHS)
   sc->pool = pool_kernel_covers(S) && pool_lds_bytes(S, RT_BLOCK) <= ctx->lds_max;
   if (sc->pool) {
     HIPCHK(allow_lds(std::max(lds_any, pool_lds_bytes(S, RT_BLOCK))));
@@ -1061,7 +1061,7 @@ static int render_device_impl(rt_ctx* ctx, const rt_scene* sc, const rt_camera* 
     HIPCHK(hipMalloc(&ctx->d_partial, need));
     ctx->partial_bytes = need;
   }
-  return render_enqueue(ctx, sc, R, C, count, sc->pool && !(p->flags & RT_FLAG_LANE_PATHS), ctx->d_queue, ctx->d_stats, ctx->d_partial, d_rgb_sum, d_argb, stats, stream);
+  return render_enqueue(ctx, sc, R, C, count, sc->pool && (p->flags & RT_FLAG_POOL_PATHS), ctx->d_queue, ctx->d_stats, ctx->d_partial, d_rgb_sum, d_argb, stats, stream);
 }
 
 // ---- the entry point that allocates nothing ------------------------------------------------
@@ -1104,7 +1104,7 @@ int rt_render_device_noalloc(rt_ctx* ctx, const rt_scene* sc, const rt_camera* c
   DCamera C;
   fill_camera(cam, p, C);
   unsigned char* base = ctx->scratch;
-  return render_enqueue(ctx, sc, R, C, false, sc->pool && !(p->flags & RT_FLAG_LANE_PATHS), reinterpret_cast<uint32_t*>(base + RT_SCRATCH_QUEUE_OFF),
+  return render_enqueue(ctx, sc, R, C, false, sc->pool && (p->flags & RT_FLAG_POOL_PATHS), reinterpret_cast<uint32_t*>(base + RT_SCRATCH_QUEUE_OFF),
                         reinterpret_cast<unsigned long long*>(base + RT_SCRATCH_STATS_OFF),
                         reinterpret_cast<float*>(base + RT_SCRATCH_SLAB_OFF), d_rgb_sum, d_argb, nullptr,
                         static_cast<hipStream_t>(hip_stream));

@@ -152,7 +152,14 @@ __global__ __launch_bounds__(RT_BLOCK, 2) void k_render_pool(RenderArgs A) {
   unsigned long long n_rays = 0, n_samples = 0;
   uint32_t prio_tick = __builtin_amdgcn_s_getreg(6148);
 
+#ifdef RT_POOL_STAMPS
+  unsigned long long sc_cyc[PS_COUNT] = {0, 0, 0, 0, 0, 0}, sc_rounds[PS_COUNT] = {0, 0, 0, 0, 0, 0}, sc_n[PS_COUNT] = {0, 0, 0, 0, 0, 0};
+  unsigned long long sc_census = 0, sc_walk_iters = 0, sc_walk_lanes = 0, ts_a = 0, ts_b = 0, ts_c = 0;
+#endif
   for (uint32_t round = 0; round < RT_POOL_MAX_ROUNDS; ++round) {
+#ifdef RT_POOL_STAMPS
+    __builtin_amdgcn_sched_barrier(0); ts_a = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
     switch (prio_tick++ & 3u) {
       case 0: __builtin_amdgcn_s_setprio(0); break;
       case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -187,6 +194,9 @@ __global__ __launch_bounds__(RT_BLOCK, 2) void k_render_pool(RenderArgs A) {
       n += __popcll(b);
     }
     pool_sync();
+#ifdef RT_POOL_STAMPS
+    __builtin_amdgcn_sched_barrier(0); ts_b = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
     const bool mine = (int)lane < n;               // (WALK takes its paths from the list itself)
     const int e = mine ? (int)Q.list[lane] : 0;
 
@@ -337,6 +347,9 @@ __global__ __launch_bounds__(RT_BLOCK, 2) void k_render_pool(RenderArgs A) {
           if (have) { Q.st(PF_NODE, we, (uint32_t)node); Q.st(PF_SPG, we, (uint32_t)sp | ((uint32_t)g << 8)); }
           break;
         }
+#ifdef RT_POOL_STAMPS
+        sc_walk_iters += 1; sc_walk_lanes += (unsigned long long)__popcll(havem);
+#endif
         // a tree is finished: on to the world's next one, or the search is over
         const bool tree_done = have && node == RT_BVH_DONE;
         if (__ballot(tree_done) != 0ull) {
@@ -460,7 +473,20 @@ __global__ __launch_bounds__(RT_BLOCK, 2) void k_render_pool(RenderArgs A) {
       }
     }
     pool_sync();
+#ifdef RT_POOL_STAMPS
+    __builtin_amdgcn_sched_barrier(0); ts_c = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+    sc_census += ts_b - ts_a;
+#pragma unroll
+    for (int s = 0; s < PS_COUNT; ++s)
+      if (stage == s) { sc_cyc[s] += ts_c - ts_b; sc_rounds[s] += 1; sc_n[s] += (unsigned long long)min(n, 64); }
+#endif
   }
+#ifdef RT_POOL_STAMPS
+  if (lane == 0) {
+    for (int s = 0; s < 5; ++s) { atomicAdd(&stats[2 + s], sc_cyc[s]); atomicAdd(&stats[2 + 5 + s], sc_rounds[s]); atomicAdd(&stats[2 + 10 + s], sc_n[s]); }
+    atomicAdd(&stats[2 + 15], sc_census); atomicAdd(&stats[2 + 16], sc_walk_iters); atomicAdd(&stats[2 + 17], sc_walk_lanes);
+  }
+#endif
 
   if (clock_wave) {
     stats[RT_STATS_CLOCK + 1] = __builtin_readcyclecounter();

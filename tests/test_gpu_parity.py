@@ -213,7 +213,9 @@ def test_sample_radiance_same_random_stream(gpu_ctx, oracle, name):
     scale = np.maximum(np.abs(orc).max(axis=1), 1e-2)
     rel = err / scale
     diverged = rel > 2e-3
-    assert diverged.mean() <= 5e-3, f"{int(diverged.sum())} of {n} samples diverged"
+    print(f"[parity] {name} per-sample radiance, same random stream: {int(diverged.sum())} of {n} samples diverged "
+          f"(a comparison on a knife edge sends the FP32 and the FP64 path different ways); median relative error {np.median(rel):.2e}")
+    assert diverged.mean() <= 1e-3, f"{int(diverged.sum())} of {n} samples diverged"   # observed: at most 2 of 6000
     assert np.median(rel) <= 1e-5
     ok = ~diverged
     assert abs(dev[ok].mean() - orc[ok].mean()) <= 1e-4 * max(orc[ok].mean(), 1e-3)
@@ -241,7 +243,7 @@ def test_render_same_random_stream(gpu_ctx, oracle, name):
     sc.close()
 
 
-@pytest.mark.parametrize("name", ["cornell-box", "cornell-smoke", "two-spheres", "two-perlin-spheres", "earth", "final-scene"])
+@pytest.mark.parametrize("name", ALL_SCENES)
 def test_render_is_the_sum_of_its_samples_bit_for_bit(gpu_ctx, name):
     """The render loop (wave-wide sphere draw in the small-scene kernels, lanes refilled in place)
     against rt_sample_batch (one lane per sample, per-lane rejection loop): draws are addressed by
@@ -249,7 +251,9 @@ def test_render_is_the_sum_of_its_samples_bit_for_bit(gpu_ctx, name):
     and with one sample per chunk the frame is their sum in sample order."""
     cfg, flat, cam = scene_bundle(name)
     sc = gpu_ctx.scene(flat)
-    W, H, spp = 29, 19, 5
+    # (tens of thousands of samples per world: a branch taken by one path in a thousand, such as a
+    # reflecting glass bounce, is still met dozens of times)
+    W, H, spp = 93, 61, 6
     p = abi.make_params(W, H, spp, 50, cfg["background"], seed=77)
     rgb, argb, st = sc.render(cam, p)
     px = np.repeat(np.arange(W * H, dtype=np.int32), spp)
@@ -259,6 +263,15 @@ def test_render_is_the_sum_of_its_samples_bit_for_bit(gpu_ctx, name):
     for k in range(spp):
         acc = acc + rad[:, :, k, :]
     assert np.array_equal(acc.view(np.uint32), rgb.astype(np.float32).view(np.uint32))
+    # worlds with trees: the kernel that re-packs paths between the stages of a bounce renders the same frame
+    if name in ("random-scene", "final-scene"):
+        pool, _, st2 = sc.render(cam, abi.make_params(W, H, spp, 50, cfg["background"], seed=77, flags=abi.RT_FLAG_POOL_PATHS))
+        assert np.array_equal(pool.view(np.uint32), rgb.view(np.uint32)) and st2["rays"] == st["rays"] and st2["samples"] == st["samples"]
+        # ... at the tiered schedule too (items of several samples, windows that straddle the image edge), and sharded
+        a, _, s1 = sc.render(cam, abi.make_params(150, 77, 131, 50, cfg["background"], seed=78, shard_index=1, shard_count=3))
+        b, _, s2 = sc.render(cam, abi.make_params(150, 77, 131, 50, cfg["background"], seed=78, shard_index=1, shard_count=3,
+                                                   flags=abi.RT_FLAG_POOL_PATHS))
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and s1["rays"] == s2["rays"]
     sc.close()
 
 

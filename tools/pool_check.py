@@ -19,7 +19,7 @@ for name in (sys.argv[1:] or ["random-scene", "final-scene"]):
     cam = build_camera(cfg, W / H)
     sc = ctx.scene(flat)
     small = {}
-    for flags in (0, abi.RT_FLAG_LANE_PATHS):
+    for flags in (0, abi.RT_FLAG_POOL_PATHS):
         p = abi.make_params(61, 45, 7, 50, cfg["background"], seed=5, flags=flags)
         rgb, argb, st = sc.render(cam, p)
         small[flags] = (rgb, st)
@@ -29,13 +29,13 @@ for name in (sys.argv[1:] or ["random-scene", "final-scene"]):
     if not same:
         d = np.abs(small[0][0] - small[2][0]).max(axis=2)
         print("  pixels differing:", int((d > 0).sum()), "max", d.max())
-    for flags in (abi.RT_FLAG_LANE_PATHS, 0):
+    for flags in (0, abi.RT_FLAG_POOL_PATHS):
         p = abi.make_params(W, H, spp, 50, cfg["background"], seed=5, flags=flags)
         sc.render(cam, abi.make_params(W, H, 1, 50, cfg["background"], flags=flags), want_argb=False)
         best = 1e9
         for _ in range(3):
             _, _, st = sc.render(cam, p, want_argb=False)
             best = min(best, st["kernel_ms"])
-        print(f"{name} {W}x{H}@{spp} {'lane-paths' if flags else 'pool      '}: kernel {best:8.2f} ms  {W * H * spp / best / 1e3:9.1f} Msamples/s", flush=True)
+        print(f"{name} {W}x{H}@{spp} {'pool      ' if flags else 'lane-paths'}: kernel {best:8.2f} ms  {W * H * spp / best / 1e3:9.1f} Msamples/s", flush=True)
     sc.close()
 ctx.close()
