@@ -343,6 +343,37 @@ int rt_scene_write(const rt_scene_desc* desc, void* bytes, uint64_t capacity, ui
 int rt_scene_create_from_memory(rt_ctx* ctx, const void* bytes, uint64_t n_bytes, rt_scene** out);
 int rt_scene_create_from_file(rt_ctx* ctx, const char* path, rt_scene** out);
 
+/*
+ * Several GPUs behind one handle, for a caller that is ONE process (the JVM): what replaces the
+ * reference's fan-out of a frame over one thread per image row and its latch (core.clj:44-48,
+ * 95,109-128). rt_multi_init binds one context per listed device; rt_multi_scene_create uploads
+ * the world to each of them; rt_multi_render runs one host thread per device, each rendering its
+ * shard through rt_render_device (RT_SPLIT_TILES: device i of n owns the 8x8 tiles t with
+ * t % n == i, all samples, and the frame is bit-identical to a single-GPU render;
+ * RT_SPLIT_SAMPLES: device i renders samples [spp*i/n, spp*(i+1)/n) of every pixel, and the FP32
+ * sums differ from a single-GPU render by re-association only), then ONE RCCL reduce(sum) of the
+ * width*height*3 FP32 accumulators onto the first device (over xGMI), the pixel post-process there,
+ * and the copy to the caller's host buffers (same meaning as rt_render's). params->shard_index /
+ * shard_count must be 0. RCCL (librccl.so) is loaded on first need: never for one device, and a
+ * list that names ONE device several times (the fan-out rehearsed on a one-GPU machine) is summed
+ * by a kernel on that device in list order. Errors of these calls are reported by
+ * rt_multi_last_error().
+ */
+typedef struct rt_multi rt_multi;
+typedef struct rt_multi_scene rt_multi_scene;
+enum { RT_SPLIT_TILES = 0, RT_SPLIT_SAMPLES = 1 };
+int rt_multi_init(const int32_t* device_ids, int32_t n_devices, rt_multi** out);
+void rt_multi_shutdown(rt_multi* m);
+int rt_multi_device_count(const rt_multi* m);
+/* Loads RCCL and makes the calls rt_multi_render makes (communicator, grouped in-place float
+ * sum-reduce to rank 0, teardown) on ONE device, where the reduce must return its input. */
+int rt_multi_selftest_rccl(int32_t device_id);
+const char* rt_multi_last_error(void);
+int rt_multi_scene_create(rt_multi* m, const rt_scene_desc* desc, rt_multi_scene** out);
+void rt_multi_scene_destroy(rt_multi_scene* scene);
+int rt_multi_render(rt_multi* m, const rt_multi_scene* scene, const rt_camera* cam, const rt_params* params,
+                    int32_t split, float* rgb_sum, uint32_t* argb, rt_stats* stats);
+
 /* What the context's device reports about itself (hipGetDeviceProperties): the numbers a caller
  * needs to price a render against the device's peak. */
 typedef struct rt_device_info {

@@ -674,6 +674,7 @@ hipError_t allow_lds(size_t bytes) {
 
 hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, float* out, uint32_t* queue,
                          unsigned long long* stats, bool count, bool pool, int grid, hipStream_t stream) {
+  (void)hipGetLastError();  // an error left behind by an unrelated earlier call is not this launch's
   if (pool) {
     const size_t lds = pool_lds_bytes(S, RT_BLOCK);
     return with_pool_kernel(S, count, [&](auto kernel) {
@@ -707,12 +708,14 @@ hipError_t render_occupancy(const DScene& S, bool count, bool pool, int* blocks_
 
 hipError_t launch_resolve(const DRender& R, const float* partial, float* rgb_sum, uint32_t* argb,
                           hipStream_t stream) {
+  (void)hipGetLastError();  // an error left behind by an unrelated earlier call is not this launch's
   int npix = R.width * R.height;
   hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, stream, R, partial, rgb_sum, argb);
   return hipGetLastError();
 }
 
 hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t* argb, hipStream_t stream) {
+  (void)hipGetLastError();  // an error left behind by an unrelated earlier call is not this launch's
   hipLaunchKernelGGL(k_tonemap, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, rgb_sum, n_pixels, spp, argb);
   return hipGetLastError();
 }
@@ -730,6 +733,7 @@ int render_variant(const DScene& S) { return pick_variant(S); }
 hipError_t launch_hit_batch(const DScene& S, int variant, int n, const float* orig3, const float* dir3,
                             const float* time, float tmin, float tmax, const float* medium_xi, rt_hit* out,
                             hipStream_t stream) {
+  (void)hipGetLastError();  // an error left behind by an unrelated earlier call is not this launch's
   const size_t lds = variant_lds_bytes(S, RT_BLOCK, variant);
   dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
 #define RT_HIT_CASE(V, MASK) case V: hipLaunchKernelGGL(k_hit_batch<MASK>, grid, block, lds, stream, S, n, orig3, dir3, time, tmin, tmax, medium_xi, out); break;
@@ -748,6 +752,7 @@ hipError_t launch_hit_batch(const DScene& S, int variant, int n, const float* or
 hipError_t launch_scatter_batch(const DScene& S, uint32_t seed_lo, uint32_t seed_hi, int n, const float* orig3,
                                 const float* dir3, const float* time, const int* px, const int* smp,
                                 const int* bounce, rt_scatter* out, hipStream_t stream) {
+  (void)hipGetLastError();  // an error left behind by an unrelated earlier call is not this launch's
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
   dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
 #define RT_SC_CASE(V, MASK) case V: hipLaunchKernelGGL(k_scatter_batch<MASK>, grid, block, lds, stream, S, seed_lo, seed_hi, n, orig3, dir3, time, px, smp, bounce, out); break;
@@ -764,6 +769,7 @@ hipError_t launch_scatter_batch(const DScene& S, uint32_t seed_lo, uint32_t seed
 
 hipError_t launch_sample_batch(const DScene& S, const DCamera& cam, const DRender& R, int n, const int* px,
                                const int* smp, float* out_rgb, hipStream_t stream) {
+  (void)hipGetLastError();  // an error left behind by an unrelated earlier call is not this launch's
   size_t lds = shade_lds_bytes(S, RT_BLOCK);
   dim3 grid((n + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
   switch (pick_variant(S)) {  // the same instantiation the render would use

@@ -17,7 +17,9 @@ EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version", "rt_scen
            "rt_tonemap_device", "rt_hit_batch", "rt_sample_batch", "rt_scene_file_size",
            "rt_scene_write", "rt_scene_create_from_memory", "rt_scene_create_from_file",
            "rt_scene_create_with", "rt_scene_get_variants", "rt_hit_batch_variant", "rt_scatter_batch",
-           "rt_render_device_noalloc", "rt_get_device_info"]
+           "rt_render_device_noalloc", "rt_get_device_info", "rt_multi_init", "rt_multi_shutdown",
+           "rt_multi_device_count", "rt_multi_selftest_rccl", "rt_multi_last_error", "rt_multi_scene_create", "rt_multi_scene_destroy",
+           "rt_multi_render"]
 
 _LIB = None
 
@@ -60,6 +62,17 @@ def load():
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_scene_destroy.restype = None
     L.rt_get_device_info.argtypes = [vp, C.POINTER(abi.rt_device_info)]
+    L.rt_multi_init.argtypes = [ip, C.c_int32, C.POINTER(vp)]
+    L.rt_multi_shutdown.argtypes = [vp]
+    L.rt_multi_shutdown.restype = None
+    L.rt_multi_device_count.argtypes = [vp]
+    L.rt_multi_selftest_rccl.argtypes = [C.c_int32]
+    L.rt_multi_last_error.restype = C.c_char_p
+    L.rt_multi_scene_create.argtypes = [vp, C.POINTER(abi.rt_scene_desc), C.POINTER(vp)]
+    L.rt_multi_scene_destroy.argtypes = [vp]
+    L.rt_multi_scene_destroy.restype = None
+    L.rt_multi_render.argtypes = [vp, vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), C.c_int32, fp, u32p,
+                                  C.POINTER(abi.rt_stats)]
     L.rt_scene_get_info.argtypes = [vp, C.POINTER(abi.rt_scene_info)]
     L.rt_render.argtypes = [vp, vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), fp, u32p,
                             C.POINTER(abi.rt_stats)]
@@ -144,6 +157,67 @@ class Context:
 
     def tonemap_device(self, d_rgb_sum_ptr: int, n_pixels: int, spp_total: int, d_argb_ptr: int, stream: int = 0):
         _check(self._L.rt_tonemap_device(self._h, d_rgb_sum_ptr, n_pixels, spp_total, d_argb_ptr, stream or None))
+
+
+class MultiContext:
+    """Several GPUs behind one handle for a single-process caller (rt_multi_*): one host thread per
+    device, one RCCL reduce onto the first device."""
+
+    def __init__(self, device_ids):
+        self._L = load()
+        self._h = C.c_void_p()
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        self._check(self._L.rt_multi_init(ids, len(device_ids), C.byref(self._h)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtError(rc, self._L.rt_multi_last_error().decode("utf-8", "replace"))
+
+    def close(self):
+        if self._h:
+            self._L.rt_multi_shutdown(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_count(self) -> int:
+        return int(self._L.rt_multi_device_count(self._h))
+
+    def scene(self, flat) -> "MultiScene":
+        return MultiScene(self, flat)
+
+
+class MultiScene:
+    def __init__(self, mctx: MultiContext, flat):
+        self.mctx = mctx
+        self.flat = flat
+        self._h = C.c_void_p()
+        mctx._check(mctx._L.rt_multi_scene_create(mctx._h, C.byref(flat.desc), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self.mctx._L.rt_multi_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, cam, params, split=abi.RT_SPLIT_TILES):
+        """-> (rgb_sum (H, W, 3) float32, argb (H, W) uint32, stats dict), host buffers as Scene.render."""
+        W, H = params.width, params.height
+        rgb = np.zeros((H, W, 3), dtype=np.float32)
+        argb = np.zeros((H, W), dtype=np.uint32)
+        st = abi.rt_stats()
+        self.mctx._check(self.mctx._L.rt_multi_render(self.mctx._h, self._h, C.byref(cam), C.byref(params), int(split),
+                                                      _fp(rgb), argb.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(st)))
+        return rgb, argb, stats_dict(st)
 
 
 class Scene:

@@ -1,0 +1,85 @@
+"""rt_multi_*: several GPUs behind one handle for a single-process caller (the stand-in for the
+reference's thread-per-row fan-out and latch, core.clj:109-128).
+
+The GPU box has ONE device, so what runs here is the one-device path and the fan-out rehearsed with
+one device named several times (shards, ordering, the sum on the first device, the post-process).
+The RCCL reduce between DISTINCT devices cannot run on this box and is untested."""
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, lib
+from util import scene_bundle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_device_equals_rt_render(gpu_ctx):
+    cfg, flat, cam = scene_bundle("cornell-box")
+    p = abi.make_params(70, 50, 9, 50, cfg["background"], seed=12)
+    sc = gpu_ctx.scene(flat)
+    rgb, argb, st = sc.render(cam, p)
+    sc.close()
+    m = lib.MultiContext([0])
+    assert m.device_count() == 1
+    ms = m.scene(flat)
+    for split in (abi.RT_SPLIT_TILES, abi.RT_SPLIT_SAMPLES):
+        r2, a2, s2 = ms.render(cam, p, split)
+        assert np.array_equal(r2, rgb) and np.array_equal(a2, argb) and s2["rays"] == st["rays"] and s2["samples"] == st["samples"]
+    ms.close()
+    m.close()
+
+
+@pytest.mark.parametrize("name,n", [("cornell-box", 2), ("cornell-box", 3), ("final-scene", 4), ("two-perlin-spheres", 8)])
+def test_fan_out_over_a_repeated_device(gpu_ctx, name, n):
+    cfg, flat, cam = scene_bundle(name)
+    W, H, spp = 61, 43, 13
+    p = abi.make_params(W, H, spp, 50, cfg["background"], seed=31)
+    sc = gpu_ctx.scene(flat)
+    rgb, argb, st = sc.render(cam, p)
+    sc.close()
+    m = lib.MultiContext([0] * n)
+    ms = m.scene(flat)
+    # tiles: disjoint pixels, every pixel summed in the single-GPU order -> the same bits
+    r2, a2, s2 = ms.render(cam, p, abi.RT_SPLIT_TILES)
+    assert np.array_equal(r2, rgb) and np.array_equal(a2, argb)
+    assert s2["rays"] == st["rays"] and s2["samples"] == W * H * spp
+    # sample slices: the same samples, FP32 sums re-associated
+    r3, a3, s3 = ms.render(cam, p, abi.RT_SPLIT_SAMPLES)
+    np.testing.assert_allclose(r3, rgb, rtol=1e-5, atol=1e-5)
+    assert s3["rays"] == st["rays"] and s3["samples"] == W * H * spp
+    ch = np.array([16, 8, 0])[:, None, None]
+    assert np.abs(((a3 >> ch) & 255).astype(int) - ((argb >> ch) & 255).astype(int)).max() <= 1
+    # fewer samples than devices: the devices left without a slice contribute zeros
+    few = abi.make_params(W, H, 2, 50, cfg["background"], seed=31)
+    sc = gpu_ctx.scene(flat)
+    ref, _, _ = sc.render(cam, few)
+    sc.close()
+    r4, _, s4 = ms.render(cam, few, abi.RT_SPLIT_SAMPLES)
+    np.testing.assert_allclose(r4, ref, rtol=1e-5, atol=1e-5)
+    assert s4["samples"] == W * H * 2
+    ms.close()
+    m.close()
+
+
+def test_multi_errors(gpu_ctx):
+    with pytest.raises(lib.RtError):
+        lib.MultiContext([])
+    with pytest.raises(lib.RtError):
+        lib.MultiContext([0, 99])
+    cfg, flat, cam = scene_bundle("cornell-box")
+    m = lib.MultiContext([0, 0])
+    ms = m.scene(flat)
+    with pytest.raises(lib.RtError) as e:
+        ms.render(cam, abi.make_params(16, 16, 2, 50, cfg["background"], shard_index=1, shard_count=2))
+    assert e.value.code == abi.RT_ERR_ARG
+    with pytest.raises(lib.RtError):
+        ms.render(cam, abi.make_params(16, 16, 2, 50, cfg["background"]), split=7)
+    ms.close()
+    m.close()
+
+
+def test_rccl_loads_and_reduces_on_one_rank(gpu_ctx):
+    """librccl.so resolves, and the calls the multi-device reduce makes run on one rank."""
+    L = lib.load()
+    rc = L.rt_multi_selftest_rccl(0)
+    assert rc == 0, L.rt_multi_last_error().decode()

@@ -1,0 +1,75 @@
+"""Image textures beyond the earth map: the two other pictures the reference ships
+(resources/stones.jpg, 512x513, and resources/map2.png, a 700x360 JPEG) through the generic
+image-texture path (texture.clj:50-81). Neither size is a power of two, so the texel index
+(int)(u * W) and its clamp to W-1 / H-1 (texture.clj:60-64) are exercised away from the easy case.
+Hit records (u, v), per-sample radiance and frames against the oracle."""
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, flatten
+from raytracing_amd.core import build_camera
+from raytracing_amd.hittables import rotate_y, sphere, translate, xy_rect, xz_rect, box
+from raytracing_amd.materials import diffuse_light, lambertian, metal
+from raytracing_amd.texture import checker_texture, image_texture, resource
+from test_gpu_parity import _check_hits
+from util import probe_rays
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(lookfrom=(9.0, 3.5, 6.0), lookat=(0.0, 1.0, 0.0), vfov=32.0, aperture=0.0, background=(0.55, 0.65, 0.9))
+
+
+def world():
+    stones = image_texture(resource("stones.jpg"))
+    map2 = image_texture(resource("map2.png"))
+    assert (stones.width, stones.height) == (512, 513) and (map2.width, map2.height) == (700, 360)
+    return [sphere([0, -1000, 0], 1000, lambertian(stones)),                 # a ground of stones
+            sphere([0, 1.5, 0], 1.5, lambertian(map2)),                       # a globe
+            sphere([-3.2, 1.0, 1.5], 1.0, lambertian(checker_texture(stones, map2))),  # image textures below a checker
+            xy_rect(-6, 6, 0, 5, -4, lambertian(map2)),                       # a textured wall: u, v of a rect
+            translate(rotate_y(box([0, 0, 0], [1.2, 1.2, 1.2], lambertian(stones)), 25), [2.5, 0, 1.5]),
+            sphere([3.0, 0.7, -1.0], 0.7, metal([0.8, 0.8, 0.8], 0.0)),
+            xz_rect(-2, 2, -2, 2, 7, diffuse_light(map2))]                    # an image as an emitter
+
+
+def test_image_textured_world(gpu_ctx, oracle):
+    flat = flatten.flatten_world(world())
+    assert flat.desc.n_images == 2
+    cam = build_camera(CFG, 1.5)
+    sc = gpu_ctx.scene(flat)
+    rv, cover = sc.variants()
+    n = 20000
+    o, d, tm = probe_rays(CFG, n, seed=41)
+    dev = sc.hit_batch(o, d, tm)
+    orc = oracle.hit_batch(flat, o, d, tm)
+    assert int(orc[:, 11].sum()) > n // 4
+    _check_hits(dev, orc, o, d, 5e-5, label="stones/map2 world probe rays")
+    for v in cover:   # every instantiation that covers the world returns the same records
+        assert sc.hit_batch(o, d, tm, variant=v).tobytes() == dev.tobytes()
+    # per-sample radiance with the shared random stream: texel fetches must agree wherever the path does
+    W, H = 60, 40
+    p = abi.make_params(W, H, 4, 50, CFG["background"], seed=19)
+    rng = np.random.default_rng(2)
+    px = rng.integers(0, W * H, 8000).astype(np.int32)
+    smp = rng.integers(0, 5000, 8000).astype(np.int32)
+    a = sc.sample_batch(cam, p, px, smp)
+    b = oracle.sample_batch(flat, cam, p, px, smp)
+    rel = np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-2)
+    print(f"[parity] stones/map2 world per-sample radiance: {int((rel > 2e-3).sum())} of 8000 diverged, median {np.median(rel):.2e}")
+    assert (rel > 2e-3).mean() <= 2e-3 and np.median(rel) <= 1e-5
+    # a frame
+    pr = abi.make_params(90, 60, 8, 50, CFG["background"], seed=23)
+    rgb, argb, st = sc.render(cam, pr)
+    orgb, oargb, orays = oracle.render(flat, cam, pr, nthreads=8)
+    assert abs(st["rays"] - orays) <= 0.005 * orays
+    off = np.abs(rgb - orgb).max(axis=2) / np.maximum(orgb.max(axis=2), 0.05) > 2e-3
+    assert off.mean() <= 0.02
+    # the frame is the sum of its samples, bit for bit
+    pxs = np.repeat(np.arange(90 * 60, dtype=np.int32), 8)
+    sm = np.tile(np.arange(8, dtype=np.int32), 90 * 60)
+    rad = sc.sample_batch(cam, pr, pxs, sm).reshape(60, 90, 8, 3)
+    acc = np.zeros((60, 90, 3), np.float32)
+    for k in range(8):
+        acc = acc + rad[:, :, k, :]
+    assert np.array_equal(acc.view(np.uint32), rgb.view(np.uint32))
+    sc.close()
