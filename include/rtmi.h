@@ -220,13 +220,22 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out);
  * library builds its own over the flattened leaves). Records and frames are identical, bit for
  * bit, whichever builder ran; only the speed of the traversal differs. */
 enum {
-  RT_BVH_DEFAULT = 0,   /* what rt_scene_create uses                                          */
-  RT_BVH_DEVICE = 1,    /* built on the GPU: Morton order, radix tree, bottom-up fit, then
-                           surface-area refinement of the tree, all in kernels                */
-  RT_BVH_HOST_SAH = 2   /* exact surface-area sweep on the host (up to 32768 primitives per
-                           group; larger groups fall back to the GPU builder)                 */
+  RT_BVH_DEFAULT = 0,      /* what rt_scene_create uses: RT_BVH_DEVICE_SAH up to 2^20 primitives per
+                              group, RT_BVH_DEVICE_LBVH beyond                                  */
+  RT_BVH_DEVICE_SAH = 1,   /* built on the GPU, top-down: exact surface-area sweep over centroid
+                              orders sorted once per axis, one launch per tree level             */
+  RT_BVH_HOST_SAH = 2,     /* the same sweep on the host, the cross-check of RT_BVH_DEVICE_SAH: both
+                              give the same tree (up to 32768 primitives per group; larger groups
+                              are built as RT_BVH_DEFAULT builds them)                           */
+  RT_BVH_DEVICE_LBVH = 3   /* built on the GPU, bottom-up: Morton order, radix tree, box fit, then
+                              rotation sweeps; the quickest build and a 3-9 % slower traversal    */
 };
 int rt_scene_create_with(rt_ctx* ctx, const rt_scene_desc* desc, int32_t bvh_builder, rt_scene** out);
+/* A digest (FNV-1a, 64 bit) of the tree records as the builder wrote them, the number of records and
+ * the height of the tallest tree: what a test compares between builders (RT_BVH_DEVICE_SAH and
+ * RT_BVH_HOST_SAH give equal digests). No counterpart in the reference, whose trees are random
+ * (base.clj:143). */
+int rt_scene_bvh_digest(rt_scene* scene, uint64_t* digest, int32_t* n_nodes, int32_t* height);
 void rt_scene_destroy(rt_scene* scene);
 
 /* The sample loop of core.clj:96-127 over this call's shard of tiles and slice of samples.

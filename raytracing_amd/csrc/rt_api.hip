@@ -90,6 +90,8 @@ struct rt_scene {
   int blocks_per_cu[2] = {0, 0};  // occupancy of k_render<false>, k_render<true>
   bool pool = false;              // the world can render on k_render_pool (RT_FLAG_POOL_PATHS)
   int pool_blocks_per_cu[2] = {0, 0};
+  const DBvhNode* d_tree = nullptr;  // the unpacked node records as the builder wrote them
+  int n_tree_nodes = 0, tree_height = 0;
   int n_shadowed_spheres = 0;     // duplicates left out of their groups' tested ranges (exact for t-min >= 0)
 };
 
@@ -458,7 +460,7 @@ void rt_scene_destroy(rt_scene* sc) {
 static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builder, rt_scene** out) {
   if (!ctx || !out) return fail(RT_ERR_ARG, "ctx or out is NULL");
   *out = nullptr;
-  if (bvh_builder < RT_BVH_DEFAULT || bvh_builder > RT_BVH_HOST_SAH) return fail(RT_ERR_ARG, "unknown BVH builder %d", bvh_builder);
+  if (bvh_builder < RT_BVH_DEFAULT || bvh_builder > RT_BVH_DEVICE_LBVH) return fail(RT_ERR_ARG, "unknown BVH builder %d", bvh_builder);
   int rc = validate_desc(d);
   if (rc) return rc;
   HIPCHK(hipSetDevice(ctx->device));
@@ -862,8 +864,8 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
   prims.resize(n_real_prims);
   S.prims = d_prims;
 
-  // BVHs for the large groups: surface-area trees from the host up to RT_SAH_MAX primitives, the
-  // device's Morton build beyond (or when the caller asks for it)
+  // BVHs for the large groups, built on the device: surface-area sweep up to RT_SWEEP_MAX primitives,
+  // Morton order beyond (or whichever builder the caller names)
   int n_bvh_nodes = 0;
   auto group_size = [](const DGroup& G) { return G.n_xy + G.n_xz + G.n_yz + G.n_sph; };
   for (auto& G : groups)
@@ -881,10 +883,15 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
     const int n_prims = group_size(G);
     if (n_prims <= RT_BRUTE_MAX) continue;
     int height = 0;
-    const bool host_sah = bvh_builder != RT_BVH_DEVICE && n_prims <= RT_SAH_MAX;
-    hipError_t e = host_sah
-                       ? build_bvh_sah(prims.data(), G.first_prim, n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0)
-                       : build_bvh(d_prims, G.first_prim, n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0);
+    int builder = bvh_builder;
+    if (builder == RT_BVH_HOST_SAH && n_prims > RT_SAH_MAX) builder = RT_BVH_DEFAULT;
+    if (builder == RT_BVH_DEFAULT) builder = n_prims <= RT_SWEEP_MAX ? RT_BVH_DEVICE_SAH : RT_BVH_DEVICE_LBVH;
+    hipError_t e =
+        builder == RT_BVH_HOST_SAH
+            ? build_bvh_sah(prims.data(), G.first_prim, n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0)
+        : builder == RT_BVH_DEVICE_SAH
+            ? build_bvh_sweep(d_prims, G.first_prim, n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0)
+            : build_bvh(d_prims, G.first_prim, n_prims, d_nodes, node_base, sc->time_lo, sc->time_hi, &height, 0);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e));
     G.bvh_root = node_base;
     node_base += n_prims - 1;
@@ -898,6 +905,9 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
     if (e != hipSuccess) return fail(RT_ERR_HIP, "BVH packing failed: %s", hipGetErrorString(e));
     S.nodes = static_cast<const DBvhNode16*>(p);
   }
+  sc->d_tree = d_nodes;
+  sc->n_tree_nodes = n_bvh_nodes;
+  sc->tree_height = max_height;
   S.bvh_stack = n_bvh_nodes ? max_height + 1 : 0;
   S.n_bvh_nodes = n_bvh_nodes;
   {
@@ -972,6 +982,26 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
 int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* d, rt_scene** out) {
   return guarded("rt_scene_create", [&] { return scene_create_impl(ctx, d, RT_BVH_DEFAULT, out); });
 }
+int rt_scene_bvh_digest(rt_scene* sc, uint64_t* digest, int32_t* n_nodes, int32_t* height) {
+  return guarded("rt_scene_bvh_digest", [&]() -> int {
+    if (!sc || !digest) return fail(RT_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(sc->ctx->device));
+    std::vector<DBvhNode> nodes((size_t)sc->n_tree_nodes);
+    if (sc->n_tree_nodes) HIPCHK(hipMemcpy(nodes.data(), sc->d_tree, sizeof(DBvhNode) * nodes.size(), hipMemcpyDeviceToHost));
+    uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a over the records' words
+    for (const DBvhNode& N : nodes) {
+      uint32_t w[14];
+      memcpy(w + 0, N.lmin, 12); memcpy(w + 3, N.lmax, 12); memcpy(w + 6, N.rmin, 12); memcpy(w + 9, N.rmax, 12);
+      memcpy(w + 12, &N.left, 4); memcpy(w + 13, &N.right, 4);
+      for (uint32_t x : w) { h ^= x; h *= 0x100000001b3ull; }
+    }
+    *digest = h;
+    if (n_nodes) *n_nodes = sc->n_tree_nodes;
+    if (height) *height = sc->tree_height;
+    return RT_OK;
+  });
+}
+
 int rt_scene_create_with(rt_ctx* ctx, const rt_scene_desc* d, int32_t bvh_builder, rt_scene** out) {
   return guarded("rt_scene_create_with", [&] { return scene_create_impl(ctx, d, bvh_builder, out); });
 }

@@ -23,6 +23,12 @@
 namespace rt {
 
 #define RT_DEV __device__ __forceinline__
+// listing build (tools/isa_histogram.py): a comment in the assembly where a phase begins
+#ifdef RT_PHASE_MARKS
+#define RT_MARK(name) { __builtin_amdgcn_sched_barrier(0); asm volatile("; RTPHASE " #name); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define RT_MARK(name)
+#endif
 
 // Scene tables are read-only for the lifetime of a launch. Reading them through the constant
 // address space lets wave-uniform accesses become scalar loads (s_load into SGPRs), so the
@@ -1000,6 +1006,7 @@ RT_DEV void hit_record(const X& ctx, const Ray& wr, const Best& best, bool want_
     bool want_uv = want_uv_always;
     if constexpr (X::has(F_IMAGE)) want_uv = want_uv || (I.mflags & DMAT_NEEDS_UV) != 0;
     prim_record<X>(S, prim, I, rx, best.t, best.root, want_uv, rec, tally);
+    RT_MARK(unwind);
     chain_unwind(ctx, I.chain, wr.d, rec, tally);
   } else {
     if constexpr (X::has(F_MEDIA)) {
@@ -1034,8 +1041,10 @@ RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, con
 #ifdef RT_STAMPS
   if (g_stamp_inner) { __builtin_amdgcn_sched_barrier(0); *g_stamp_inner = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #endif
+  RT_MARK(media);
   if (!skip_media) media_hit(ctx, wr, tmin, g, bounce, medium_xi, best, tally);
   if (best.prim == -1) return false;
+  RT_MARK(record);
   hit_record(ctx, wr, best, want_uv_always, rec, tally);
   return true;
 }

@@ -108,6 +108,9 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 // and written over the event slots of the stats buffer. Never timed, never shipped.
 #ifdef RT_STAMPS
 #define RT_STAMP(var) { __builtin_amdgcn_sched_barrier(0); var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#elif defined(RT_PHASE_MARKS)
+// listing build (tools/isa_histogram.py): a comment in the assembly where each phase of the loop begins
+#define RT_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("; RTPHASE " #var); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define RT_STAMP(var)
 #endif
@@ -421,6 +424,9 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
         }
       }
     }
+#ifdef RT_PHASE_MARKS
+    RT_STAMP(ts4);
+#endif
 #ifdef RT_STAMPS
     RT_STAMP(ts4);
     c_queue += ts1 - ts0; c_cam += ts2 - ts1; c_hit += ts3 - ts2; c_shade += ts4 - ts3; c_iters += 1; c_groups += tsi - ts2;

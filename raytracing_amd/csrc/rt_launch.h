@@ -44,6 +44,12 @@ hipError_t launch_sample_batch(const DScene& S, const DCamera& cam, const DRende
 hipError_t build_bvh(const DPrim* d_prims, int first, int n, DBvhNode* d_nodes, int node_base, float time_lo,
                      float time_hi, int* height, hipStream_t stream);
 
+// The same tree contract, built on the GPU top-down by the surface-area heuristic (exact sweep over
+// presorted centroid orders, one launch per level). Gives the tree build_bvh_sah gives.
+#define RT_SWEEP_MAX (1 << 20)
+hipError_t build_bvh_sweep(const DPrim* d_prims, int first, int n, DBvhNode* d_nodes, int node_base, float time_lo,
+                           float time_hi, int* height, hipStream_t stream);
+
 // The same tree contract, built on the host by the surface-area heuristic (exact sweep): for
 // groups of up to RT_SAH_MAX primitives. h_prims is the host copy of the primitive records.
 #define RT_SAH_MAX 32768

@@ -16,7 +16,7 @@ EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version", "rt_scen
            "rt_scene_destroy", "rt_scene_get_info", "rt_render", "rt_render_device",
            "rt_tonemap_device", "rt_hit_batch", "rt_sample_batch", "rt_scene_file_size",
            "rt_scene_write", "rt_scene_create_from_memory", "rt_scene_create_from_file",
-           "rt_scene_create_with", "rt_scene_get_variants", "rt_hit_batch_variant", "rt_scatter_batch",
+           "rt_scene_create_with", "rt_scene_bvh_digest", "rt_scene_get_variants", "rt_hit_batch_variant", "rt_scatter_batch",
            "rt_render_device_noalloc", "rt_get_device_info", "rt_multi_init", "rt_multi_shutdown",
            "rt_multi_device_count", "rt_multi_selftest_rccl", "rt_multi_last_error", "rt_multi_scene_create", "rt_multi_scene_destroy",
            "rt_multi_render"]
@@ -56,6 +56,7 @@ def load():
     L.rt_scene_create.argtypes = [vp, C.POINTER(abi.rt_scene_desc), C.POINTER(vp)]
     L.rt_scene_create_with.argtypes = [vp, C.POINTER(abi.rt_scene_desc), C.c_int32, C.POINTER(vp)]
     L.rt_scene_get_variants.argtypes = [vp, ip, u32p]
+    L.rt_scene_bvh_digest.argtypes = [vp, C.POINTER(C.c_uint64), ip, ip]
     L.rt_hit_batch_variant.argtypes = [vp, vp, C.c_int32, C.c_int32, fp, fp, fp, C.c_float, C.c_float, fp,
                                        C.POINTER(abi.rt_hit)]
     L.rt_scatter_batch.argtypes = [vp, vp, C.c_uint64, C.c_int32, fp, fp, fp, ip, ip, ip, C.POINTER(abi.rt_scatter)]
@@ -280,6 +281,12 @@ class Scene:
         array; allocates nothing, returns no statistics, refuses requests beyond the array's size."""
         _check(self._L.rt_render_device_noalloc(self.ctx._h, self._h, C.byref(cam), C.byref(params),
                                                 d_rgb_sum_ptr or None, d_argb_ptr or None, stream or None))
+
+    def bvh_digest(self):
+        """-> (64-bit digest of the tree records, number of records, height of the tallest tree)."""
+        d, n, h = C.c_uint64(0), C.c_int32(0), C.c_int32(0)
+        _check(self._L.rt_scene_bvh_digest(self._h, C.byref(d), C.byref(n), C.byref(h)))
+        return d.value, n.value, h.value
 
     def variants(self):
         """-> (instantiation the render uses, list of all instantiations that cover the world)."""

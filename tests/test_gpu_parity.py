@@ -89,27 +89,34 @@ def test_hit_records_probe_rays(gpu_ctx, oracle, name):
 
 
 @pytest.mark.parametrize("name", ["random-scene", "final-scene"])
-def test_both_tree_builders_give_the_same_records(gpu_ctx, name):
+def test_all_tree_builders_give_the_same_records(gpu_ctx, name):
     """The closest hit does not depend on the shape of the tree (exact ties are settled by scan
-    order, not by visiting order): the host's surface-area tree and the device's Morton tree must
-    return identical records, bit for bit, and identical frames."""
+    order, not by visiting order): the surface-area trees (device and host) and the device's Morton
+    tree must return identical records, bit for bit, and identical frames. The device's
+    surface-area sweep and the host's are the same algorithm with the same rounding: they must
+    give the same TREE, record for record (digest, record count, height)."""
     cfg, flat, cam = scene_bundle(name)
     n = 20000
     o, d, tm = probe_rays(cfg, n, seed=23)
     nm = flat.desc.n_media
     xi = np.random.default_rng(4).random((n, max(nm, 1))).astype(np.float32) if nm else None
     p = abi.make_params(24, 16, 3, 50, cfg["background"], seed=5)
-    out = []
-    for builder in (abi.RT_BVH_HOST_SAH, abi.RT_BVH_DEVICE, abi.RT_BVH_DEFAULT):
+    out, trees = [], {}
+    for builder in (abi.RT_BVH_HOST_SAH, abi.RT_BVH_DEVICE_SAH, abi.RT_BVH_DEVICE_LBVH, abi.RT_BVH_DEFAULT):
         sc = gpu_ctx.scene(flat, bvh_builder=builder)
+        trees[builder] = sc.bvh_digest()
         hits = sc.hit_batch(o, d, tm, medium_xi=xi)
         rgb, argb, st = sc.render(cam, p)
         out.append((hits.tobytes(), rgb.tobytes(), st["rays"]))
         sc.close()
-    for k in (1, 2):
+    for k in (1, 2, 3):
         assert out[0][0] == out[k][0]
         assert out[0][1] == out[k][1]
         assert out[0][2] == out[k][2]
+    assert trees[abi.RT_BVH_DEVICE_SAH] == trees[abi.RT_BVH_HOST_SAH]
+    assert trees[abi.RT_BVH_DEFAULT] == trees[abi.RT_BVH_DEVICE_SAH]      # the device sweep is what a scene gets
+    assert trees[abi.RT_BVH_DEVICE_LBVH][1] == trees[abi.RT_BVH_HOST_SAH][1]
+    assert trees[abi.RT_BVH_DEVICE_LBVH][0] != trees[abi.RT_BVH_HOST_SAH][0]
 
 
 @pytest.mark.parametrize("name", ALL_SCENES)
