@@ -659,6 +659,56 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
             ++n_box;
           }
         }
+        // Five (or six, of several materials) rects that are faces of ONE axis-aligned box, the room of
+        // the Cornell worlds (scenes.clj:76-81): the same slab test with the missing face marked -1.
+        // Every XY rect left is tried as a z face; the z extent comes from an XZ or YZ rect that
+        // spans the XY rect's x or y extent and starts or ends on its plane.
+        int n_open = 0;
+        for (int p = o_xy; p < o_xz; ++p) {
+          if (used(p)) continue;
+          const float x0 = F5(p)[0], x1 = F5(p)[1], y0 = F5(p)[2], y1 = F5(p)[3], kz = F5(p)[4];
+          if (!(x0 < x1 && y0 < y1)) continue;
+          std::vector<std::array<float, 2>> z_extents;
+          auto offer = [&](int lo, int hi, float a0, float a1) {
+            for (int i = lo; i < hi; ++i) {
+              const float* f = F5(i);
+              if (used(i) || f[0] != a0 || f[1] != a1 || !(f[2] < f[3]) || (f[2] != kz && f[3] != kz)) continue;
+              z_extents.push_back({f[2], f[3]});
+            }
+          };
+          offer(o_xz, o_yz, x0, x1);
+          offer(o_yz, o_end, y0, y1);
+          for (const auto& ze : z_extents) {
+            const float z0 = ze[0], z1 = ze[1];
+            auto find_face = [&](int lo, int hi, float a0, float a1, float b0, float b1, float k, int taken) {
+              for (int i = lo; i < hi; ++i) {
+                const float* f = F5(i);
+                if (!used(i) && i != taken && f[0] == a0 && f[1] == a1 && f[2] == b0 && f[3] == b1 && f[4] == k) return i;
+              }
+              return -1;
+            };
+            int face[6];
+            face[0] = find_face(o_xy, o_xz, x0, x1, y0, y1, z0, -1);
+            face[1] = find_face(o_xy, o_xz, x0, x1, y0, y1, z1, face[0]);
+            face[2] = find_face(o_xz, o_yz, x0, x1, z0, z1, y0, -1);
+            face[3] = find_face(o_xz, o_yz, x0, x1, z0, z1, y1, face[2]);
+            face[4] = find_face(o_yz, o_end, y0, y1, z0, z1, x0, -1);
+            face[5] = find_face(o_yz, o_end, y0, y1, z0, z1, x1, face[4]);
+            int n_faces = 0;
+            for (int i : face) n_faces += i >= 0;
+            if (n_faces != 5) continue;
+            for (float v : {x0, x1, y0, y1, z0, z1}) brute_boxes.push_back(v);
+            for (int i : face) {
+              float bits;
+              std::memcpy(&bits, &i, 4);
+              brute_boxes.push_back(bits);
+              if (i >= 0) used(i) = 1;
+            }
+            ++n_open;
+            break;
+          }
+        }
+        G.flags |= n_open << DGROUP_OPEN_SHIFT;
         // pair records per orientation (see DScene.brute_rects) for the rects no box took
         int off = G.first_prim, loose_n[3] = {0, 0, 0}, ti = 0;
         for (int n_t : {G.n_xy, G.n_xz, G.n_yz}) {

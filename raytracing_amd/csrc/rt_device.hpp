@@ -253,6 +253,7 @@ struct Ctx {
   unsigned long long* st_leaf;      // diagnostic build: wave cycles spent in BVH leaf tests,
   unsigned long long* st_walk;      //   in the walk between them, and the number of leaf rounds
   unsigned long long* st_rounds;
+  unsigned long long* st_grp;       //   wave cycles per surface group (8 slots) and, in slot 7, in the media
 #endif
 };
 
@@ -669,6 +670,17 @@ RT_DEV bool box_accept(const BoxSlab& s, float tmin, float tmax, float& t) {
   const int sgn = __float_as_int(s.tf - s.tn) | __float_as_int(t - tmin) | __float_as_int(tmax - t);
   return sgn >= 0;
 }
+// The same for a box with ONE face missing (five rects that are faces of one axis-aligned box: the
+// walls of the Cornell room, scenes.clj:76-81). The scan still accepts exactly the faces the ray
+// pierces, the entry and the exit of the slab, minus the missing one; pm is the plane parameter
+// of the missing face. (Where the missing plane ties with a neighbour's, on the rim of the opening,
+// the reference's scan would take the neighbour; such a ray is lost here.)
+RT_DEV bool open_box_accept(const BoxSlab& s, float pm, float tmin, float tmax, float& t) {
+  const bool entry = s.tn >= tmin && s.tn != pm;
+  t = entry ? s.tn : s.tf;
+  const int sgn = __float_as_int(s.tf - s.tn) | __float_as_int(t - tmin) | __float_as_int(tmax - t);
+  return sgn >= 0 && (entry || s.tf != pm);
+}
 template <class T>
 RT_DEV void brute_boxes(const float RT_CONST* B, int n_box, const RayX& r, float tmin, Best& best, T& tally) {
   for (int b = 0; b < n_box; ++b) {
@@ -694,6 +706,36 @@ RT_DEV void brute_boxes(const float RT_CONST* B, int n_box, const RayX& r, float
     best.prim = ok ? face : best.prim;
   }
 }
+// The records with one face missing (its index is -1), a loop of their own so that the closed boxes'
+// loop stays as lean as it is.
+template <class T>
+RT_DEV void brute_open_boxes(const float RT_CONST* B, int n_open, const RayX& r, float tmin, Best& best, T& tally) {
+  for (int b = 0; b < n_open; ++b) {
+    float w[RT_BOX_STRIDE];
+#pragma unroll
+    for (int q = 0; q < RT_BOX_STRIDE; ++q) w[q] = B[b * RT_BOX_STRIDE + q];
+    asm volatile("" ::"s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]), "s"(w[4]), "s"(w[5]), "s"(w[6]), "s"(w[7]), "s"(w[8]),
+                 "s"(w[9]), "s"(w[10]), "s"(w[11]));
+    tally.template add<RT_EV_BOX_SLAB>();
+    const BoxSlab s = box_slab(w, r);
+    float pm = s.tz.x;  // (the conditions are wave-uniform)
+    pm = __float_as_int(w[7]) < 0 ? s.tz.y : pm;
+    pm = __float_as_int(w[8]) < 0 ? s.ty.x : pm;
+    pm = __float_as_int(w[9]) < 0 ? s.ty.y : pm;
+    pm = __float_as_int(w[10]) < 0 ? s.tx.x : pm;
+    pm = __float_as_int(w[11]) < 0 ? s.tx.y : pm;
+    float t;
+    const bool ok = open_box_accept(s, pm, tmin, best.t, t);
+    int face = __float_as_int(w[6]);
+    face = s.tz.y == t ? __float_as_int(w[7]) : face;
+    face = s.ty.x == t ? __float_as_int(w[8]) : face;
+    face = s.ty.y == t ? __float_as_int(w[9]) : face;
+    face = s.tx.x == t ? __float_as_int(w[10]) : face;
+    face = s.tx.y == t ? __float_as_int(w[11]) : face;
+    best.t = ok ? t : best.t;
+    best.prim = ok ? face : best.prim;
+  }
+}
 
 // The brute-force loops of group G (rect pairs, closed boxes, spheres in scan order) for the
 // group-space ray r.
@@ -706,6 +748,7 @@ RT_DEV void brute_group_hit(const DScene& S, const DGroup RT_CONST& G, const Ray
   brute_rects<pair_batch<X>()>(cptr(S.brute_rects) + G.first_rect * RT_PAIR_STRIDE, loose & 255, (loose >> 8) & 255, (loose >> 16) & 255,
               r, tmin, best, tally);
   brute_boxes(cptr(S.brute_boxes) + G.first_box * RT_BOX_STRIDE, loose >> 24, r, tmin, best, tally);
+  brute_open_boxes(cptr(S.brute_boxes) + (G.first_box + (loose >> 24)) * RT_BOX_STRIDE, (G.flags >> DGROUP_OPEN_SHIFT) & 255, r, tmin, best, tally);
   first += G.n_xy + G.n_xz + G.n_yz;
   if constexpr (X::has(F_SPHERES)) {
     const int n_sph = G.n_sph;
@@ -1037,12 +1080,28 @@ RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, con
   const DScene& S = ctx.S;
   Best best{tmax, -1, 0.0};
   const int n_surface = S.n_surface_groups;
+#ifdef RT_STAMPS
+  for (int gi = 0; gi < n_surface; ++gi) {
+    __builtin_amdgcn_sched_barrier(0); const unsigned long long g0 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+    group_hit(ctx, gi, wr, tmin, best, tally, (double)tmin);
+    __builtin_amdgcn_sched_barrier(0); const unsigned long long g1 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+    if (ctx.st_grp) ctx.st_grp[gi < 6 ? gi : 6] += g1 - g0;
+  }
+#else
   for (int gi = 0; gi < n_surface; ++gi) group_hit(ctx, gi, wr, tmin, best, tally, (double)tmin);
+#endif
 #ifdef RT_STAMPS
   if (g_stamp_inner) { __builtin_amdgcn_sched_barrier(0); *g_stamp_inner = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #endif
   RT_MARK(media);
+#ifdef RT_STAMPS
+  __builtin_amdgcn_sched_barrier(0); const unsigned long long m0 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
   if (!skip_media) media_hit(ctx, wr, tmin, g, bounce, medium_xi, best, tally);
+#ifdef RT_STAMPS
+  __builtin_amdgcn_sched_barrier(0); const unsigned long long m1 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+  if (ctx.st_grp) ctx.st_grp[7] += m1 - m0;
+#endif
   if (best.prim == -1) return false;
   RT_MARK(record);
   hit_record(ctx, wr, best, want_uv_always, rec, tally);

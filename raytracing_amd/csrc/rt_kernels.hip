@@ -85,7 +85,7 @@ __device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* ld
   X.lds_stack = reinterpret_cast<int*>(lds + vec_bytes + perm_bytes + info_bytes + xch_bytes) + threadIdx.x;
   X.stack_stride = blockDim.x;
 #ifdef RT_STAMPS
-  X.st_leaf = X.st_walk = X.st_rounds = nullptr;
+  X.st_leaf = X.st_walk = X.st_rounds = nullptr; X.st_grp = nullptr;
 #endif
   return X;
 }
@@ -210,7 +210,8 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
   Ctx<FEAT> X = make_ctx<FEAT>(A.S, lds);
 #ifdef RT_STAMPS
   unsigned long long c_leaf = 0, c_walk = 0, c_rounds = 0;
-  X.st_leaf = &c_leaf; X.st_walk = &c_walk; X.st_rounds = &c_rounds;
+  unsigned long long c_grp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  X.st_leaf = &c_leaf; X.st_walk = &c_walk; X.st_rounds = &c_rounds; X.st_grp = c_grp;
 #endif
   const DRender& R = A.R;
   float* __restrict__ out = A.out;
@@ -452,6 +453,11 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       w = w2 > w ? w2 : w; l = l2 > l ? l2 : l; r = r2 > r ? r2 : r;
     }
     if (lane == 0) { atomicAdd(&stats[2 + 9], w); atomicAdd(&stats[2 + 10], l); atomicAdd(&stats[2 + 11], r); }
+    for (int q = 0; q < 8; ++q) {  // per group: the lane that was in the group longest = the wave's time
+      unsigned long long v = c_grp[q];
+      for (int off = 32; off >= 1; off >>= 1) { unsigned long long v2 = __shfl_xor(v, off, 64); v = v2 > v ? v2 : v; }
+      if (lane == 0) atomicAdd(&stats[2 + 12 + q], v);
+    }
   }
 #endif
   // One atomic per wave and counter, not per lane: half a million same-address atomics at the end

@@ -121,6 +121,8 @@ struct DGroup64 {  // the same motion in FP64, for DGROUP_SPHERES_UNDER_CHAIN gr
   double rc, rs, bx, by, bz;
   double pad[3];
 };
+#define DGROUP_OPEN_SHIFT 8            // flags bits 8-15: boxes with one face missing, stored after the
+                                      // closed ones in DScene.brute_boxes (the missing face's index is -1)
 #define DGROUP_SPHERES_UNDER_CHAIN 1  // spheres below a non-identity chain: the ray is carried into
                                       // chain space in FP64 (as a float hi + lo pair)
 

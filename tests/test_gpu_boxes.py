@@ -80,6 +80,75 @@ def test_edges_corners_and_faces_exactly(gpu_ctx, oracle):
     sc.close()
 
 
+def _room(missing, order=("x1", "x0", "y0", "y1", "z1", "z0")):
+    """Five rects that are faces of the box [0,8] x [0,6] x [0,10] (the Cornell room of scenes.clj:76-81 has
+    z = 0 open), each wall with its own material, plus a light below the ceiling and a block inside."""
+    faces = {"z0": xy_rect(0, 8, 0, 6, 0, WHITE), "z1": xy_rect(0, 8, 0, 6, 10, WHITE),
+             "y0": xz_rect(0, 8, 0, 10, 0, WHITE), "y1": xz_rect(0, 8, 0, 10, 6, RED),
+             "x0": yz_rect(0, 6, 0, 10, 0, RED), "x1": yz_rect(0, 6, 0, 10, 8, GREEN)}
+    walls = [faces[k] for k in order if k != missing]
+    return walls[:2] + [xz_rect(3, 5, 4, 6, 5.9, WHITE)] + walls[2:] + [translate(rotate_y(box([0, 0, 0], [2, 3, 2], WHITE), 20), [3, 0, 4])]
+
+
+@pytest.mark.parametrize("missing", ["z0", "z1", "y0", "y1", "x0", "x1"])
+def test_room_with_one_face_open_against_the_rect_by_rect_oracle(gpu_ctx, oracle, missing):
+    """Five faces of one box are intersected as one slab test with the missing face marked: rays from
+    inside, from outside through the opening, from outside onto the backs of the walls, along the axes."""
+    flat = flatten.flatten_world(_room(missing))
+    sc = gpu_ctx.scene(flat)
+    rng = np.random.default_rng(3)
+    n = 40000
+    o = rng.uniform(-6, 16, (n, 3))
+    o[: n // 2] = rng.uniform(0.1, 5.9, (n // 2, 3)) * np.array([8 / 6, 1.0, 10 / 6])   # inside the room
+    d = rng.normal(size=(n, 3))
+    k = n // 8
+    d[n // 2: n // 2 + k] = 0
+    d[np.arange(n // 2, n // 2 + k), rng.integers(0, 3, k)] = rng.choice([-1.0, 1.0], k)
+    o, d = o.astype(np.float32), d.astype(np.float32)
+    dev = sc.hit_batch(o, d)
+    orc = oracle.hit_batch(flat, o, d)
+    assert int(orc[:, 11].sum()) > n // 3
+    assert int((orc[: n // 2, 11] < 0.5).sum()) > 500       # rays that leave through the opening
+    _check_hits(dev, orc, o, d, 1e-4)
+    sc.close()
+
+
+def test_room_lattice_rays_exactly(gpu_ctx, oracle):
+    """Corners and edges of the open room approached along power-of-two directions: exact arithmetic on
+    both sides, so ties between walls must fall the same way. Targets on the rim of the opening are
+    left out (there the missing plane ties with a wall's). The walls are listed XY, XZ, YZ: the device scans
+    rects type by type, so only in that order are ties ACROSS orientations the reference's (the later wall wins)."""
+    room = _room("z0", order=("z1", "z0", "y0", "y1", "x0", "x1"))
+    flat = flatten.flatten_world(room[:2] + room[3:6])     # the five walls alone
+    sc = gpu_ctx.scene(flat)
+    targets = [(x, y, z) for x in (0, 4, 8) for y in (0, 2, 6) for z in (2, 6, 10)]
+    dirs = [(sx * a, sy * b, sz * c) for (a, b, c) in ((4, 4, 4), (8, 4, 2), (2, 8, 4), (4, 2, 8), (16, 1, 1))
+            for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
+    o, d = [], []
+    for tg in targets:
+        for dv in dirs:
+            for back in (1.0, 0.125):
+                o.append(np.subtract(tg, np.multiply(dv, back)))
+                d.append(dv)
+    o, d = np.float64(o), np.float64(d)
+    # rays that cross the plane of the opening exactly on its rim are left out (exact in FP64: lattice values)
+    tz = -o[:, 2] / d[:, 2]
+    x, y = o[:, 0] + tz * d[:, 0], o[:, 1] + tz * d[:, 1]
+    rim = ((x == 0) | (x == 8) | (y == 0) | (y == 6)) & (x >= 0) & (x <= 8) & (y >= 0) & (y <= 6)
+    o, d = np.float32(o[~rim]), np.float32(d[~rim])
+    assert len(o) > 1500
+    dev = sc.hit_batch(o, d)
+    orc = oracle.hit_batch(flat, o, d)
+    same = (dev["hit"] == orc[:, 11].astype(int))
+    both = same & (dev["hit"] == 1)
+    assert same.all()
+    assert int(both.sum()) > 1000
+    assert np.array_equal(dev["t"][both], orc[both, 0].astype(np.float32))
+    assert np.array_equal(dev["normal"][both], orc[both, 4:7].astype(np.float32))
+    assert np.array_equal(dev["mat_id"][both], orc[both, 10].astype(np.int32))
+    sc.close()
+
+
 def test_box_as_medium_boundary(gpu_ctx, oracle):
     """constant_medium.clj:11-20 asks its boundary for the entry over (-inf, inf) and for the exit
     after it: both come out of the same slab test."""

@@ -403,8 +403,8 @@ def test_event_counters_are_consistent(gpu_ctx):
     ev = st1["events"]
     assert st1["samples"] == W * H * spp == ev["camera_ray"] == ev["accumulate"]
     assert st1["rays"] == st0["rays"]
-    assert ev["rect_test"] == 6 * st1["rays"]           # 6 walls, brute force
-    assert ev["box_slab"] == 2 * st1["rays"]            # the two blocks: one slab test each, not six rect tests
+    assert ev["rect_test"] == 1 * st1["rays"]           # the light; the five walls are one open-box slab test
+    assert ev["box_slab"] == 3 * st1["rays"]            # the room and the two blocks: one slab test each
     # one collapsed ray motion per ray per group (3 groups) + one more for every winner's record
     assert ev["rotate_y_ray"] == 3 * st1["rays"] + ev["rect_record"]
     assert ev["rotate_y_rec"] == ev["translate_rec"] <= ev["rect_record"]

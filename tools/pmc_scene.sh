@@ -38,7 +38,7 @@ ms = float(re.search(r"kernel\s+([0-9.]+) ms", line[-1]).group(1)) if line else 
 if per.get("SQ_ACTIVE_INST_VALU"):
     print(f"active-lane ratio  SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64) = {per['SQ_THREAD_CYCLES_VALU'] / (per['SQ_ACTIVE_INST_VALU'] * 64):.3f}")
 if ms and per.get("SQ_INSTS_VALU"):
-    print(f"SIMD cycles (2.4 GHz, 1024 SIMDs) per VALU wave-instruction = {ms * 1e-3 * 2.4e9 * 1024 / per['SQ_INSTS_VALU']:.2f}  (timing of the profiled run)")
+    print(f"SIMD cycles (2.39 GHz measured, 1024 SIMDs) per VALU wave-instruction = {ms * 1e-3 * 2.39e9 * 1024 / per['SQ_INSTS_VALU']:.2f}  (timing of the profiled run)")
     print(f"VALU : SALU : VMEM-read : LDS wave-instructions = 1 : {per['SQ_INSTS_SALU'] / per['SQ_INSTS_VALU']:.2f} : "
           f"{per.get('SQ_INSTS_VMEM_RD', 0) / per['SQ_INSTS_VALU']:.3f} : {per.get('SQ_INSTS_LDS', 0) / per['SQ_INSTS_VALU']:.3f}")
 if ms and "FETCH_SIZE" in per:

@@ -26,6 +26,9 @@ print(f"  of closest_hit: group loops {grp / it:9.1f}, record + unwind {(h - grp
 if ev[11]:
     print(f"  of group loops: BVH walk {ev[9] / it:9.1f}, BVH leaf tests {ev[10] / it:9.1f} (longest lane of each wave); "
           f"leaf rounds per wave-iteration {ev[11] / it:.2f}")
+if any(ev[12:20]):
+    print("  per surface group (wave cycles per wave-iteration): " + "  ".join(f"g{q} {ev[12 + q] / it:.1f}" for q in range(7) if ev[12 + q])
+          + f"  | media {ev[19] / it:.1f}")
 mx, mn_inv, sq = ev[6], ev[7], ev[8]
 if mx:
     import math
