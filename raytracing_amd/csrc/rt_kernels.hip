@@ -37,7 +37,7 @@
 #define RT_WAVES_SMOKE 5
 #endif
 #ifndef RT_WAVES_LEAN
-#define RT_WAVES_LEAN 7
+#define RT_WAVES_LEAN 6
 #endif
 
 namespace rt {
@@ -163,6 +163,8 @@ constexpr int waves_per_simd(uint32_t feat, bool count) {
   if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : RT_WAVES_SPH;
   // the smoke worlds' kernel spills at 72 and at 80 registers: five waves measured 5 % faster than seven
   if (feat & F_MEDIA) return count ? 4 : RT_WAVES_SMOKE;
+  // the rect-only kernel: six waves (85 registers, nothing spilled) measured 7 to 9 % faster than seven
+  // (71 registers, 14 of them spilled and re-read in every record), five the same as six
   return count ? 4 : RT_WAVES_LEAN;
 }
 

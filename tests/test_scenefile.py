@@ -52,6 +52,27 @@ def test_file_size_and_header():
     assert L.rt_scene_file_size(C.byref(bad)) == 0 and b"root" in L.rt_last_error()
 
 
+def test_validation_covers_the_texture_index_of_every_material():
+    """A metal or dielectric material never reads its texture index, but the index still has to be -1
+    or a texture of the description: scene creation looks at it for every material."""
+    from raytracing_amd.hittables import sphere
+    from raytracing_amd.materials import Metal, lambertian
+    from raytracing_amd import flatten
+    flat = flatten.flatten_world([sphere([0, 0, 0], 1.0, Metal([0.5, 0.5, 0.5], 0.1)), sphere([3, 0, 0], 1.0, lambertian([0.2, 0.3, 0.4]))])
+    L = lib.load()
+    assert L.rt_scene_file_size(C.byref(flat.desc)) > 0
+    n = flat.desc.n_mats
+    types = [flat.desc.mat_type[i] for i in range(n)]
+    metal = types.index(abi.RT_MAT_METAL)
+    for bad_index in (0x7fffffff, flat.desc.n_tex, -2):
+        tex = (C.c_int32 * n)(*[flat.desc.mat_tex[i] for i in range(n)])
+        tex[metal] = bad_index
+        bad = abi.rt_scene_desc.from_buffer_copy(flat.desc)
+        bad.mat_tex = C.cast(tex, type(bad.mat_tex))
+        assert L.rt_scene_file_size(C.byref(bad)) == 0, bad_index
+        assert b"tex" in L.rt_last_error()
+
+
 def test_reader_rejects_malformed_blobs():
     _, flat = setup("earth", 1)
     data = scenefile.dumps(flat)
