@@ -30,9 +30,9 @@ out = {
     "algorithmic_bytes_per_launch": W * H * n_chunks * 12,
     "note": "the path kernel writes one 12-byte partial sum per (pixel, sample chunk): 112 chunks x 1024^2 x 12 B = 1.41 GB. "
             "The lanes of a window finish their items thousands of iterations apart, so a 128-byte line is written in "
-            "12-byte pieces at different times and leaves L2 partly written more than once; the register spills' "
-            "evicted lines add to it. Under 3 GB in 129 ms is about 20 GB/s of 8 000: the kernel is nowhere near HBM-bound. "
-            "Scene data is served from LDS and the scalar cache.",
+            "12-byte pieces at different times and some lines leave L2 partly written more than once: "
+            f"{(fetch + write) / (W * H * n_chunks * 12):.2f} x the algorithmic bytes (1.95 x while the kernel still spilled registers). "
+            "About 14 GB/s of 8 000: the kernel is nowhere near HBM-bound. Scene data is served from LDS and the scalar cache.",
     "valu_wave_insts_per_launch": per.get("SQ_INSTS_VALU"),
     "salu_wave_insts_per_launch": per.get("SQ_INSTS_SALU"),
     "active_lane_ratio": round(per["SQ_THREAD_CYCLES_VALU"] / (per["SQ_ACTIVE_INST_VALU"] * 64), 4),

@@ -5,7 +5,7 @@ set -u
 cd "$(dirname "$0")/.."
 REPO=$PWD
 TAG=${1:-r01}; shift || true
-ARGS=${@:-"--steps 2 --warmup 1 --no-cpu-baseline"}
+ARGS=${@:-"--steps 2 --warmup 1 --no-cpu-baseline --no-other-configs"}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
