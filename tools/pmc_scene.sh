@@ -1,12 +1,12 @@
 #!/bin/bash
 # PMC passes for one scene through tools/scene_bench.py: instruction counts, waits, HBM bytes read and
-# written (one rocprofv3 run per pass). Usage (inside gpurun): bash tools/pmc_scene.sh <tag> <scene>
+# written (one rocprofv3 run per pass). Usage (inside gpurun): bash tools/pmc_scene.sh <tag> <scene> [--pool]
 # Prints a summary of the path kernel per launch: active-lane ratio, SIMD cycles per VALU instruction,
 # HBM GB/s (FETCH_SIZE doubled: gfx950 counts wide reads at half).
 set -u
 cd "$(dirname "$0")/.."
 REPO=$PWD
-TAG=$1; SCENE=$2
+TAG=$1; SCENE=$2; EXTRA=${3:-}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp PYTHONPATH=$REPO
@@ -15,7 +15,7 @@ i=1
 for P in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" \
          "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" \
          "FETCH_SIZE" "WRITE_SIZE"; do
-  timeout -s KILL 200 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $REPO/tools/scene_bench.py $SCENE > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $REPO/tools/scene_bench.py $SCENE $EXTRA > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; exit 1; }
   i=$((i+1))
 done
 python3 - $OUT $SCENE <<'PY'

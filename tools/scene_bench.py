@@ -1,5 +1,5 @@
 """Throughput of the path kernel on every reference world at its full benchmark size
-(reduced spp): Msamples/s, rays/sample, kernel ms. Usage: python tools/scene_bench.py [--full] [scene ...]
+(reduced spp): Msamples/s, rays/sample, kernel ms. Usage: python tools/scene_bench.py [--full] [--pool] [scene ...]
 --full: the sample counts of the benchmark configurations (random-scene @500, the texture worlds and the
 Cornell boxes @1000; final-scene @100 of its 10 000, one GPU's share of a sample split being 1 250)."""
 import sys
@@ -19,7 +19,8 @@ CASES = {  # scene -> (W, H, spp)
 FULL = {"cornell-box": 1000, "cornell-smoke": 1000, "random-scene": 500, "two-spheres": 1000,
         "two-perlin-spheres": 1000, "earth": 1000, "simple-light": 1000, "final-scene": 100}
 full = "--full" in sys.argv[1:]
-names = [a for a in sys.argv[1:] if a != "--full"] or list(CASES)
+pool = "--pool" in sys.argv[1:]   # the re-packing kernel (RT_FLAG_POOL_PATHS) where the world can use it
+names = [a for a in sys.argv[1:] if a not in ("--full", "--pool")] or list(CASES)
 ctx = lib.Context(0)
 for name in names:
     W, H, spp = CASES[name]
@@ -28,7 +29,7 @@ for name in names:
     cfg, flat = setup(name, 1)
     cam = build_camera(cfg, W / H)
     sc = ctx.scene(flat)
-    p = abi.make_params(W, H, spp, 50, cfg["background"], seed=0x5EED0001)
+    p = abi.make_params(W, H, spp, 50, cfg["background"], seed=0x5EED0001, flags=abi.RT_FLAG_POOL_PATHS if pool else 0)
     sc.render_device(cam, p, 0, 0, want_stats=True)  # warm-up
     st = sc.render_device(cam, p, 0, 0, want_stats=True)
     ms = st["kernel_ms"]
