@@ -119,6 +119,46 @@ def test_all_tree_builders_give_the_same_records(gpu_ctx, name):
     assert trees[abi.RT_BVH_DEVICE_LBVH][0] != trees[abi.RT_BVH_HOST_SAH][0]
 
 
+@pytest.mark.parametrize("n,seed", [(17, 1), (300, 2), (2000, 3), (9000, 4)])
+def test_device_sweep_builds_the_host_sweeps_tree(gpu_ctx, n, seed):
+    """Random mixes of spheres, moving spheres and rects of all three orientations, sizes from one workgroup
+    chunk to dozens (the scans carry across 256-element chunks), with exact duplicates and shared centroids
+    (ties in the sort and in the cost): the GPU's surface-area sweep and the host's give the same tree,
+    and the records do not depend on which one ran."""
+    from raytracing_amd import flatten
+    from raytracing_amd.hittables import moving_sphere, sphere, xy_rect, xz_rect, yz_rect
+    from raytracing_amd.materials import lambertian
+    rng = np.random.default_rng(seed)
+    mat = lambertian([0.5, 0.5, 0.5])
+    world = []
+    for i in range(n):
+        c = rng.uniform(-50, 50, 3)
+        kind = i % 5
+        if kind == 0:
+            world.append(sphere(c, float(rng.uniform(0.2, 3.0)), mat))
+        elif kind == 1:
+            world.append(moving_sphere(c, c + rng.uniform(-1, 1, 3), 0.0, 1.0, float(rng.uniform(0.2, 2.0)), mat))
+        else:
+            a0, b0 = c[0], c[1]
+            a1, b1 = a0 + rng.uniform(0.5, 6.0), b0 + rng.uniform(0.5, 6.0)
+            k = float(int(c[2])) + 0.5 * (i % 2)      # `^long k` truncates: integral and half-way planes
+            world.append((xy_rect, xz_rect, yz_rect)[kind - 2](a0, a1, b0, b1, k, mat))
+    world += world[: max(2, n // 50)]                  # exact duplicates
+    world.append(sphere(world[0].center if hasattr(world[0], "center") else [0, 0, 0], 0.7, mat))  # a shared centroid
+    flat = flatten.flatten_world(world)
+    o = rng.uniform(-60, 60, (4000, 3)).astype(np.float32)
+    d = rng.normal(size=(4000, 3)).astype(np.float32)
+    tm = rng.random(4000).astype(np.float32)
+    got = {}
+    for builder in (abi.RT_BVH_HOST_SAH, abi.RT_BVH_DEVICE_SAH, abi.RT_BVH_DEVICE_LBVH):
+        sc = gpu_ctx.scene(flat, bvh_builder=builder)
+        got[builder] = (sc.bvh_digest(), sc.hit_batch(o, d, tm).tobytes())
+        sc.close()
+    assert got[abi.RT_BVH_DEVICE_SAH][0] == got[abi.RT_BVH_HOST_SAH][0]
+    assert got[abi.RT_BVH_DEVICE_SAH][0][1] > 0                   # there is a tree
+    assert got[abi.RT_BVH_DEVICE_SAH][1] == got[abi.RT_BVH_HOST_SAH][1] == got[abi.RT_BVH_DEVICE_LBVH][1]
+
+
 @pytest.mark.parametrize("name", ALL_SCENES)
 def test_hit_records_path_rays(gpu_ctx, oracle, name):
     """Rays that real paths produce: they start ON surfaces (t-min handling, grazing bounces,
