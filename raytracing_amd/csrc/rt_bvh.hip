@@ -302,11 +302,18 @@ __global__ void k_pack_nodes(const DBvhNode* __restrict__ nodes, DBvhNode16* __r
   if (i >= n) return;
   const DBvhNode N = nodes[i];
   DBvhNode16 P;
+  // centre to the nearest half, then the half-extent that still covers both bounds FROM THAT CENTRE,
+  // rounded up (the differences are exact in FP64): the packed box can only be larger
+  auto pack = [](float mn, float mx, uint16_t& c16, uint16_t& h16) {
+    const __half c = __float2half_rn(0.5f * mn + 0.5f * mx);
+    const double cd = (double)__half2float(c);
+    const double h = fmax((double)mx - cd, cd - (double)mn);
+    c16 = __half_as_ushort(c);
+    h16 = __half_as_ushort(__float2half_ru((float)(h * (1.0 + 1e-6))));
+  };
   for (int a = 0; a < 3; ++a) {
-    P.lmin[a] = __half_as_ushort(__float2half_rd(N.lmin[a]));
-    P.lmax[a] = __half_as_ushort(__float2half_ru(N.lmax[a]));
-    P.rmin[a] = __half_as_ushort(__float2half_rd(N.rmin[a]));
-    P.rmax[a] = __half_as_ushort(__float2half_ru(N.rmax[a]));
+    pack(N.lmin[a], N.lmax[a], P.lc[a], P.lh[a]);
+    pack(N.rmin[a], N.rmax[a], P.rc[a], P.rh[a]);
   }
   P.left = N.left; P.right = N.right;
   packed[i] = P;

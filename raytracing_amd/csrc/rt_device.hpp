@@ -469,13 +469,18 @@ RT_DEV RayX group_ray(const DScene& S, int g, int gflags, float rc, float rs, fl
 // t = bound * (1/d) - o/d: less exact than (bound - o) * (1/d) when the origin is far from the box
 // relative to its size, by a few ulps of o/d; the boxes' outward rounding covers that many times.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-RT_DEV bool slab16(_Float16 mnx, _Float16 mny, _Float16 mnz, _Float16 mxx, _Float16 mxy, _Float16 mxz, V3 inv, V3 oi,
+// The box arrives as centre and half-extent (FP16): the ray's parameter at the centre plane of an axis is
+// tc = c * (1/d) - o/d and the slab is tc -+ h * |1/d|, so the near and the far parameter need no min/max to
+// tell them apart: nine FMAs per box instead of six FMAs and six min/max.
+RT_DEV bool slab16(_Float16 cx, _Float16 cy, _Float16 cz, _Float16 hx, _Float16 hy, _Float16 hz, V3 inv, V3 oi,
                    float tmin, float tmax, float& tnear) {
-  const float t0x = fmaf((float)mnx, inv.x, -oi.x), t1x = fmaf((float)mxx, inv.x, -oi.x);
-  const float t0y = fmaf((float)mny, inv.y, -oi.y), t1y = fmaf((float)mxy, inv.y, -oi.y);
-  const float t0z = fmaf((float)mnz, inv.z, -oi.z), t1z = fmaf((float)mxz, inv.z, -oi.z);
-  const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-  const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+  const float tcx = fmaf((float)cx, inv.x, -oi.x), tcy = fmaf((float)cy, inv.y, -oi.y), tcz = fmaf((float)cz, inv.z, -oi.z);
+  const float ax = fabsf(inv.x), ay = fabsf(inv.y), az = fabsf(inv.z);
+  const float n_x = fmaf((float)hx, -ax, tcx), f_x = fmaf((float)hx, ax, tcx);
+  const float n_y = fmaf((float)hy, -ay, tcy), f_y = fmaf((float)hy, ay, tcy);
+  const float n_z = fmaf((float)hz, -az, tcz), f_z = fmaf((float)hz, az, tcz);
+  const float tn = fmaxf(fmaxf(n_x, n_y), fmaxf(n_z, tmin));
+  const float tf = fminf(fminf(f_x, f_y), fminf(f_z, tmax));
   tnear = tn;
   return tn <= tf;
 }
@@ -516,7 +521,7 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
     while ((unsigned)node < (unsigned)RT_BVH_DONE) {  // internal
       const u4 q0 = nodes4[node * 2 + 0];
       const u4 q1 = nodes4[node * 2 + 1];
-      // halves in storage order: lmin xyz, lmax xyz, rmin xyz, rmax xyz
+      // halves in storage order: left centre xyz, left half-extent xyz, right centre xyz, right half-extent xyz
       // (plain scalars first: a bit cast applied to a vector element reads the vector's first one)
       const uint32_t w0 = q0.x, w1 = q0.y, w2 = q0.z, w3 = q0.w, w4 = q1.x, w5 = q1.y;
       const h2 a0 = __builtin_bit_cast(h2, w0), a1 = __builtin_bit_cast(h2, w1), a2 = __builtin_bit_cast(h2, w2);

@@ -158,13 +158,14 @@ struct DBvhNode {
   int32_t left, right;
   int32_t pad[2];
 };
-// What the traversal reads: the same node in 32 bytes, the boxes as FP16 rounded outwards (minima
-// down, maxima up), so a step fetches half as much per lane and the slab test takes its operands
-// straight from the halves (v_fma_mix_f32). A box can only grow: nothing is culled that the FP32
-// node would keep.
+// What the traversal reads: the same node in 32 bytes, each box as centre and half-extent in FP16 (the
+// centre to the nearest half, the half-extent rounded up from what that centre needs to cover both
+// bounds), so a step fetches half as much per lane and the slab test takes its operands straight
+// from the halves (v_fma_mix_f32, nine per box and no min/max to sort near from far). A box can only
+// grow: nothing is culled that the FP32 node would keep.
 struct DBvhNode16 {
-  uint16_t lmin[3], lmax[3];
-  uint16_t rmin[3], rmax[3];
+  uint16_t lc[3], lh[3];   // left child: centre, half-extent
+  uint16_t rc[3], rh[3];   // right child
   int32_t left, right;
 };
 
