@@ -476,9 +476,10 @@ RT_DEV bool slab16(_Float16 cx, _Float16 cy, _Float16 cz, _Float16 hx, _Float16 
                    float tmin, float tmax, float& tnear) {
   const float tcx = fmaf((float)cx, inv.x, -oi.x), tcy = fmaf((float)cy, inv.y, -oi.y), tcz = fmaf((float)cz, inv.z, -oi.z);
   const float ax = fabsf(inv.x), ay = fabsf(inv.y), az = fabsf(inv.z);
-  const float n_x = fmaf((float)hx, -ax, tcx), f_x = fmaf((float)hx, ax, tcx);
-  const float n_y = fmaf((float)hy, -ay, tcy), f_y = fmaf((float)hy, ay, tcy);
-  const float n_z = fmaf((float)hz, -az, tcz), f_z = fmaf((float)hz, az, tcz);
+  // (the half-extent is the operand that is negated: with -|1/d| the compiler keeps three more registers)
+  const float n_x = fmaf(-(float)hx, ax, tcx), f_x = fmaf((float)hx, ax, tcx);
+  const float n_y = fmaf(-(float)hy, ay, tcy), f_y = fmaf((float)hy, ay, tcy);
+  const float n_z = fmaf(-(float)hz, az, tcz), f_z = fmaf((float)hz, az, tcz);
   const float tn = fmaxf(fmaxf(n_x, n_y), fmaxf(n_z, tmin));
   const float tf = fminf(fminf(f_x, f_y), fminf(f_z, tmax));
   tnear = tn;

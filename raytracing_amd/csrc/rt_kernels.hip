@@ -27,6 +27,9 @@
 #ifndef RT_WAVES_DEEP
 #define RT_WAVES_DEEP 4
 #endif
+#ifndef RT_WAVES_NOISE
+#define RT_WAVES_NOISE 6
+#endif
 #ifndef RT_REGEN_SMOKE
 #define RT_REGEN_SMOKE 1
 #endif
@@ -159,6 +162,9 @@ constexpr int waves_per_simd(uint32_t feat, bool count) {
   // the all-features kernel fits 128 registers with 26 spilled (the FP64 arccosine and arctangent of
   // the sphere u/v once made it want 211): four waves measured 9 % faster than three on the texture
   // worlds, five 20 % slower everywhere (F_DEEP is the same code under a knob of its own)
+  // the noise-only kernel wants 105 registers where the all-features one wants 128 and spills: measured
+  // at 3 / 4 / 5 / 6 / 7 / 8 waves: 94 / 96 / 91 / 90 / 96 / 112 ms on the Perlin spheres (all-features: 109)
+  if ((feat & F_NOISE) && !(feat & (F_BVH | F_MEDIA | F_CHAINS))) return count ? 2 : RT_WAVES_NOISE;
   if (feat & F_NOISE) return count ? 2 : ((feat & F_DEEP) ? RT_WAVES_DEEP : RT_WAVES_ALL);
   if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : RT_WAVES_SPH;
   // the smoke worlds' kernel spills at 72 and at 80 registers: five waves measured 5 % faster than seven
@@ -603,11 +609,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_sample_batch(DScene S, DCamera cam
 //   V_SMOKE  + constant media with isotropic phase functions (the Cornell smoke box)
 //   V_SPH    spheres and rects at the top level, BVHs, metal / dielectric, checker and image
 //            textures: everything of the first book (the random-spheres world, the earth)
-//   V_ALL    everything the reference's worlds use
+//   V_NOISE  spheres and rects at the top level with Perlin-noise and checker textures (the Perlin
+//            spheres, the lit Perlin sphere)
+//   V_ALL    everything the reference's worlds use (V_ALL_DEEP: the instantiation that renders it)
 //   V_FULL   + media whose boundary is any hittable (V_ALL answers one-sphere and one-box boundaries)
 constexpr uint32_t V_RECT = F_CHAINS | F_SMALL;
 constexpr uint32_t V_SMOKE = F_CHAINS | F_MEDIA | F_SMALL;
-constexpr uint32_t V_SPH = F_SPHERES | F_BVH | F_SPECULAR | F_TEXTURES;
+constexpr uint32_t V_SPH = F_SPHERES | F_BVH | F_SPECULAR | F_TEXTURES | F_IMAGE;
+constexpr uint32_t V_NOISE = F_SPHERES | F_TEXTURES | F_NOISE;
 constexpr uint32_t V_ALL = F_ALL;
 constexpr uint32_t V_ALL_DEEP = F_ALL | F_DEEP;  // everything, for worlds with BVHs
 constexpr uint32_t V_FULL = F_ALL | F_MEDIA_ANY;
@@ -618,7 +627,7 @@ int pick_variant(const DScene& S) {
   if (small && (S.features & ~V_RECT) == 0) return 0;
   if (small && (S.features & ~V_SMOKE) == 0) return 1;
   if ((S.features & ~V_SPH) == 0) return 2;
-  return (S.features & F_BVH) ? 4 : 3;
+  return (S.features & ~V_NOISE) == 0 ? 3 : 4;
 }
 
 // LDS per workgroup of instantiation `variant` (the F_SMALL ones, 0 and 1, keep the record tables there).
@@ -661,8 +670,8 @@ auto with_render_kernel(const DScene& S, bool count, F&& f) {
     case 3: return f(k_render<V_SMOKE, true>);
     case 4: return f(k_render<V_SPH, false>);
     case 5: return f(k_render<V_SPH, true>);
-    case 6: return f(k_render<V_ALL, false>);
-    case 7: return f(k_render<V_ALL, true>);
+    case 6: return f(k_render<V_NOISE, false>);
+    case 7: return f(k_render<V_NOISE, true>);
     case 8: return f(k_render<V_ALL_DEEP, false>);
     case 9: return f(k_render<V_ALL, true>);
     case 10: return f(k_render<V_FULL, false>);
@@ -678,9 +687,10 @@ hipError_t allow_lds(size_t bytes) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   };
 #define RT_ALLOW(MASK) allow(k_render<MASK, false>); allow(k_render<MASK, true>); allow(k_hit_batch<MASK>); allow(k_sample_batch<MASK>); allow(k_scatter_batch<MASK>);
-  RT_ALLOW(V_RECT) RT_ALLOW(V_SMOKE) RT_ALLOW(V_SPH) RT_ALLOW(V_ALL) RT_ALLOW(V_FULL)
+  RT_ALLOW(V_RECT) RT_ALLOW(V_SMOKE) RT_ALLOW(V_SPH) RT_ALLOW(V_NOISE) RT_ALLOW(V_FULL)
 #undef RT_ALLOW
-  allow(k_render<V_ALL_DEEP, false>); allow(k_hit_batch<V_ALL_DEEP>);
+  allow(k_render<V_ALL_DEEP, false>); allow(k_render<V_ALL, true>); allow(k_hit_batch<V_ALL_DEEP>);
+  allow(k_sample_batch<V_ALL>); allow(k_scatter_batch<V_ALL>);
   allow(k_render_pool<V_SPH, false>); allow(k_render_pool<V_SPH, true>);
   allow(k_render_pool<V_ALL_DEEP, false>); allow(k_render_pool<V_ALL, true>);
   return e;
@@ -737,7 +747,7 @@ hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t*
 // Does instantiation `variant` (0 V_RECT .. 5 V_FULL) support everything the scene needs?
 bool variant_covers(const DScene& S, int variant) {
   const bool small = S.n_prims <= RT_LDS_PRIMS && S.n_chains <= RT_LDS_CHAINS;
-  const uint32_t masks[6] = {V_RECT, V_SMOKE, V_SPH, V_ALL, V_ALL_DEEP, V_FULL};
+  const uint32_t masks[6] = {V_RECT, V_SMOKE, V_SPH, V_NOISE, V_ALL_DEEP, V_FULL};
   if (variant < 0 || variant > 5) return false;
   if ((masks[variant] & F_SMALL) && !small) return false;
   return (S.features & ~masks[variant]) == 0;
@@ -755,7 +765,7 @@ hipError_t launch_hit_batch(const DScene& S, int variant, int n, const float* or
     RT_HIT_CASE(0, V_RECT)
     RT_HIT_CASE(1, V_SMOKE)
     RT_HIT_CASE(2, V_SPH)
-    RT_HIT_CASE(3, V_ALL)
+    RT_HIT_CASE(3, V_NOISE)
     RT_HIT_CASE(4, V_ALL_DEEP)
     default: hipLaunchKernelGGL(k_hit_batch<V_FULL>, grid, block, lds, stream, S, n, orig3, dir3, time, tmin, tmax, medium_xi, out); break;
   }
@@ -774,6 +784,7 @@ hipError_t launch_scatter_batch(const DScene& S, uint32_t seed_lo, uint32_t seed
     RT_SC_CASE(0, V_RECT)
     RT_SC_CASE(1, V_SMOKE)
     RT_SC_CASE(2, V_SPH)
+    RT_SC_CASE(3, V_NOISE)
     RT_SC_CASE(5, V_FULL)
     default: hipLaunchKernelGGL(k_scatter_batch<V_ALL>, grid, block, lds, stream, S, seed_lo, seed_hi, n, orig3, dir3, time, px, smp, bounce, out); break;
   }
@@ -790,6 +801,7 @@ hipError_t launch_sample_batch(const DScene& S, const DCamera& cam, const DRende
     case 0: hipLaunchKernelGGL(k_sample_batch<V_RECT>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     case 1: hipLaunchKernelGGL(k_sample_batch<V_SMOKE>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     case 2: hipLaunchKernelGGL(k_sample_batch<V_SPH>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
+    case 3: hipLaunchKernelGGL(k_sample_batch<V_NOISE>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     case 5: hipLaunchKernelGGL(k_sample_batch<V_FULL>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     default: hipLaunchKernelGGL(k_sample_batch<V_ALL>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
   }

@@ -24,7 +24,7 @@ size_t pool_lds_bytes(const DScene& S, int block);
 hipError_t launch_resolve(const DRender& R, const float* partial, float* rgb_sum, uint32_t* argb,
                           hipStream_t stream);
 hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t* argb, hipStream_t stream);
-// Instantiations of the kernels, smallest first: 0 V_RECT, 1 V_SMOKE, 2 V_SPH, 3 V_ALL, 4 V_ALL_DEEP, 5 V_FULL.
+// Instantiations of the kernels, smallest first: 0 V_RECT, 1 V_SMOKE, 2 V_SPH, 3 V_NOISE, 4 V_ALL_DEEP, 5 V_FULL.
 #define RT_N_VARIANTS 6
 bool variant_covers(const DScene& S, int variant);
 int render_variant(const DScene& S);

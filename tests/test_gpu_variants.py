@@ -21,7 +21,7 @@ SEED = 0x5EED0001
 
 # what each world renders on (instantiation index as in include/rtmi.h)
 RENDERS_ON = {"cornell-box": 0, "cornell-smoke": 1, "two-spheres": 2, "random-scene": 2,
-              "two-perlin-spheres": 3, "earth": 3, "simple-light": 3, "final-scene": 4}
+              "earth": 2, "two-perlin-spheres": 3, "simple-light": 3, "final-scene": 4}
 
 
 @pytest.mark.parametrize("name", ALL_SCENES)
