@@ -30,6 +30,9 @@
 #ifndef RT_WAVES_NOISE
 #define RT_WAVES_NOISE 6
 #endif
+#ifndef RT_WAVES_LIST
+#define RT_WAVES_LIST 7
+#endif
 #ifndef RT_REGEN_SMOKE
 #define RT_REGEN_SMOKE 1
 #endif
@@ -166,6 +169,9 @@ constexpr int waves_per_simd(uint32_t feat, bool count) {
   // at 3 / 4 / 5 / 6 / 7 / 8 waves: 94 / 96 / 91 / 90 / 96 / 112 ms on the Perlin spheres (all-features: 109)
   if ((feat & F_NOISE) && !(feat & (F_BVH | F_MEDIA | F_CHAINS))) return count ? 2 : RT_WAVES_NOISE;
   if (feat & F_NOISE) return count ? 2 : ((feat & F_DEEP) ? RT_WAVES_DEEP : RT_WAVES_ALL);
+  // spheres in plain lists: at 5 / 6 / 7 / 8 waves the earth takes 22.5 / 21.2 / 21.0 / 22.6 ms (23.5 on the
+  // kernel that also walks trees), the two checkered spheres 73.3 / 70.0 / 69.8 / 75.1 (75.9)
+  if ((feat & F_SPHERES) && !(feat & (F_BVH | F_NOISE | F_MEDIA | F_CHAINS))) return count ? 2 : RT_WAVES_LIST;
   if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : RT_WAVES_SPH;
   // the smoke worlds' kernel spills at 72 and at 80 registers: five waves measured 5 % faster than seven
   if (feat & F_MEDIA) return count ? 4 : RT_WAVES_SMOKE;
@@ -607,15 +613,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_sample_batch(DScene S, DCamera cam
 //   V_RECT   axis-aligned rects under translate/rotate-y chains, solid-colour Lambertians and lights
 //            (the Cornell box)
 //   V_SMOKE  + constant media with isotropic phase functions (the Cornell smoke box)
-//   V_SPH    spheres and rects at the top level, BVHs, metal / dielectric, checker and image
-//            textures: everything of the first book (the random-spheres world, the earth)
+//   V_LIST   spheres and rects in plain lists (no tree), metal / dielectric, checker and image textures
+//            (the two checkered spheres, the earth)
+//   V_SPH    + BVHs: everything of the first book (the random-spheres world)
 //   V_NOISE  spheres and rects at the top level with Perlin-noise and checker textures (the Perlin
 //            spheres, the lit Perlin sphere)
 //   V_ALL    everything the reference's worlds use (V_ALL_DEEP: the instantiation that renders it)
 //   V_FULL   + media whose boundary is any hittable (V_ALL answers one-sphere and one-box boundaries)
 constexpr uint32_t V_RECT = F_CHAINS | F_SMALL;
 constexpr uint32_t V_SMOKE = F_CHAINS | F_MEDIA | F_SMALL;
-constexpr uint32_t V_SPH = F_SPHERES | F_BVH | F_SPECULAR | F_TEXTURES | F_IMAGE;
+constexpr uint32_t V_LIST = F_SPHERES | F_SPECULAR | F_TEXTURES | F_IMAGE;
+constexpr uint32_t V_SPH = V_LIST | F_BVH;
 constexpr uint32_t V_NOISE = F_SPHERES | F_TEXTURES | F_NOISE;
 constexpr uint32_t V_ALL = F_ALL;
 constexpr uint32_t V_ALL_DEEP = F_ALL | F_DEEP;  // everything, for worlds with BVHs
@@ -623,11 +631,12 @@ constexpr uint32_t V_FULL = F_ALL | F_MEDIA_ANY;
 
 int pick_variant(const DScene& S) {
   const bool small = S.n_prims <= RT_LDS_PRIMS && S.n_chains <= RT_LDS_CHAINS;
-  if (S.features & F_MEDIA_ANY) return 5;
+  if (S.features & F_MEDIA_ANY) return 6;
   if (small && (S.features & ~V_RECT) == 0) return 0;
   if (small && (S.features & ~V_SMOKE) == 0) return 1;
-  if ((S.features & ~V_SPH) == 0) return 2;
-  return (S.features & ~V_NOISE) == 0 ? 3 : 4;
+  if ((S.features & ~V_LIST) == 0) return 2;
+  if ((S.features & ~V_SPH) == 0) return 3;
+  return (S.features & ~V_NOISE) == 0 ? 4 : 5;
 }
 
 // LDS per workgroup of instantiation `variant` (the F_SMALL ones, 0 and 1, keep the record tables there).
@@ -647,7 +656,7 @@ namespace rt {
 // and 8-bit stack depths bound the trees it takes.
 bool pool_kernel_covers(const DScene& S) {
   const int v = pick_variant(S);
-  return (v == 2 || v == 4) && S.first_bvh_group >= 0 && S.n_bvh_nodes < 32768 && S.n_prims < 32768 &&
+  return (v == 3 || v == 5) && S.first_bvh_group >= 0 && S.n_bvh_nodes < 32768 && S.n_prims < 32768 &&
          S.bvh_stack < 256 && S.n_groups < (1 << 23);
 }
 size_t pool_lds_bytes(const DScene& S, int block) {
@@ -657,7 +666,7 @@ size_t pool_lds_bytes(const DScene& S, int block) {
 }
 template <class F>
 auto with_pool_kernel(const DScene& S, bool count, F&& f) {
-  if (pick_variant(S) == 2) return count ? f(k_render_pool<V_SPH, true>) : f(k_render_pool<V_SPH, false>);
+  if (pick_variant(S) == 3) return count ? f(k_render_pool<V_SPH, true>) : f(k_render_pool<V_SPH, false>);
   return count ? f(k_render_pool<V_ALL, true>) : f(k_render_pool<V_ALL_DEEP, false>);
 }
 
@@ -668,13 +677,15 @@ auto with_render_kernel(const DScene& S, bool count, F&& f) {
     case 1: return f(k_render<V_RECT, true>);
     case 2: return f(k_render<V_SMOKE, false>);
     case 3: return f(k_render<V_SMOKE, true>);
-    case 4: return f(k_render<V_SPH, false>);
-    case 5: return f(k_render<V_SPH, true>);
-    case 6: return f(k_render<V_NOISE, false>);
-    case 7: return f(k_render<V_NOISE, true>);
-    case 8: return f(k_render<V_ALL_DEEP, false>);
-    case 9: return f(k_render<V_ALL, true>);
-    case 10: return f(k_render<V_FULL, false>);
+    case 4: return f(k_render<V_LIST, false>);
+    case 5: return f(k_render<V_LIST, true>);
+    case 6: return f(k_render<V_SPH, false>);
+    case 7: return f(k_render<V_SPH, true>);
+    case 8: return f(k_render<V_NOISE, false>);
+    case 9: return f(k_render<V_NOISE, true>);
+    case 10: return f(k_render<V_ALL_DEEP, false>);
+    case 11: return f(k_render<V_ALL, true>);
+    case 12: return f(k_render<V_FULL, false>);
     default: return f(k_render<V_FULL, true>);
   }
 }
@@ -687,7 +698,7 @@ hipError_t allow_lds(size_t bytes) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   };
 #define RT_ALLOW(MASK) allow(k_render<MASK, false>); allow(k_render<MASK, true>); allow(k_hit_batch<MASK>); allow(k_sample_batch<MASK>); allow(k_scatter_batch<MASK>);
-  RT_ALLOW(V_RECT) RT_ALLOW(V_SMOKE) RT_ALLOW(V_SPH) RT_ALLOW(V_NOISE) RT_ALLOW(V_FULL)
+  RT_ALLOW(V_RECT) RT_ALLOW(V_SMOKE) RT_ALLOW(V_LIST) RT_ALLOW(V_SPH) RT_ALLOW(V_NOISE) RT_ALLOW(V_FULL)
 #undef RT_ALLOW
   allow(k_render<V_ALL_DEEP, false>); allow(k_render<V_ALL, true>); allow(k_hit_batch<V_ALL_DEEP>);
   allow(k_sample_batch<V_ALL>); allow(k_scatter_batch<V_ALL>);
@@ -744,11 +755,11 @@ hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t*
   return hipGetLastError();
 }
 
-// Does instantiation `variant` (0 V_RECT .. 5 V_FULL) support everything the scene needs?
+// Does instantiation `variant` (0 V_RECT .. 6 V_FULL) support everything the scene needs?
 bool variant_covers(const DScene& S, int variant) {
   const bool small = S.n_prims <= RT_LDS_PRIMS && S.n_chains <= RT_LDS_CHAINS;
-  const uint32_t masks[6] = {V_RECT, V_SMOKE, V_SPH, V_NOISE, V_ALL_DEEP, V_FULL};
-  if (variant < 0 || variant > 5) return false;
+  const uint32_t masks[RT_N_VARIANTS] = {V_RECT, V_SMOKE, V_LIST, V_SPH, V_NOISE, V_ALL_DEEP, V_FULL};
+  if (variant < 0 || variant >= RT_N_VARIANTS) return false;
   if ((masks[variant] & F_SMALL) && !small) return false;
   return (S.features & ~masks[variant]) == 0;
 }
@@ -764,9 +775,10 @@ hipError_t launch_hit_batch(const DScene& S, int variant, int n, const float* or
   switch (variant) {
     RT_HIT_CASE(0, V_RECT)
     RT_HIT_CASE(1, V_SMOKE)
-    RT_HIT_CASE(2, V_SPH)
-    RT_HIT_CASE(3, V_NOISE)
-    RT_HIT_CASE(4, V_ALL_DEEP)
+    RT_HIT_CASE(2, V_LIST)
+    RT_HIT_CASE(3, V_SPH)
+    RT_HIT_CASE(4, V_NOISE)
+    RT_HIT_CASE(5, V_ALL_DEEP)
     default: hipLaunchKernelGGL(k_hit_batch<V_FULL>, grid, block, lds, stream, S, n, orig3, dir3, time, tmin, tmax, medium_xi, out); break;
   }
 #undef RT_HIT_CASE
@@ -783,9 +795,10 @@ hipError_t launch_scatter_batch(const DScene& S, uint32_t seed_lo, uint32_t seed
   switch (pick_variant(S)) {  // the same instantiation the render would use
     RT_SC_CASE(0, V_RECT)
     RT_SC_CASE(1, V_SMOKE)
-    RT_SC_CASE(2, V_SPH)
-    RT_SC_CASE(3, V_NOISE)
-    RT_SC_CASE(5, V_FULL)
+    RT_SC_CASE(2, V_LIST)
+    RT_SC_CASE(3, V_SPH)
+    RT_SC_CASE(4, V_NOISE)
+    RT_SC_CASE(6, V_FULL)
     default: hipLaunchKernelGGL(k_scatter_batch<V_ALL>, grid, block, lds, stream, S, seed_lo, seed_hi, n, orig3, dir3, time, px, smp, bounce, out); break;
   }
 #undef RT_SC_CASE
@@ -800,9 +813,10 @@ hipError_t launch_sample_batch(const DScene& S, const DCamera& cam, const DRende
   switch (pick_variant(S)) {  // the same instantiation the render would use
     case 0: hipLaunchKernelGGL(k_sample_batch<V_RECT>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     case 1: hipLaunchKernelGGL(k_sample_batch<V_SMOKE>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
-    case 2: hipLaunchKernelGGL(k_sample_batch<V_SPH>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
-    case 3: hipLaunchKernelGGL(k_sample_batch<V_NOISE>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
-    case 5: hipLaunchKernelGGL(k_sample_batch<V_FULL>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
+    case 2: hipLaunchKernelGGL(k_sample_batch<V_LIST>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
+    case 3: hipLaunchKernelGGL(k_sample_batch<V_SPH>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
+    case 4: hipLaunchKernelGGL(k_sample_batch<V_NOISE>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
+    case 6: hipLaunchKernelGGL(k_sample_batch<V_FULL>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     default: hipLaunchKernelGGL(k_sample_batch<V_ALL>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
   }
   return hipGetLastError();

@@ -24,8 +24,10 @@ size_t pool_lds_bytes(const DScene& S, int block);
 hipError_t launch_resolve(const DRender& R, const float* partial, float* rgb_sum, uint32_t* argb,
                           hipStream_t stream);
 hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t* argb, hipStream_t stream);
-// Instantiations of the kernels, smallest first: 0 V_RECT, 1 V_SMOKE, 2 V_SPH, 3 V_NOISE, 4 V_ALL_DEEP, 5 V_FULL.
-#define RT_N_VARIANTS 6
+// Instantiations of the kernels: 0 V_RECT, 1 V_SMOKE, 2 V_LIST, 3 V_SPH, 4 V_NOISE, 5 V_ALL_DEEP, 6 V_FULL.
+#ifndef RT_N_VARIANTS
+#define RT_N_VARIANTS 7
+#endif
 bool variant_covers(const DScene& S, int variant);
 int render_variant(const DScene& S);
 size_t variant_lds_bytes(const DScene& S, int block, int variant);
