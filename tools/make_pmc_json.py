@@ -13,6 +13,8 @@ tag = sys.argv[1]
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 out = {}
 for path in sorted(glob.glob(os.path.join(root, f"{tag}_pmc_*.txt"))):
+    if "_pmc_pool_" in os.path.basename(path):
+        continue  # the re-packing kernel's counters are a study, not what bench.py's configurations run on
     text = open(path).read()
     head = re.search(r"^(\S+)\s+(\d+)x(\d+) @\s*(\d+): kernel\s+([0-9.]+) ms", text, re.M)
     if not head:
