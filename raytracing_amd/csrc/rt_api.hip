@@ -626,7 +626,14 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
           const float *a = F5(i), *b = F5(j);
           return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3] && prims[(size_t)i].mat == prims[(size_t)j].mat;
         };
-        int n_box = 0;
+        struct BoxCand { float bounds[6]; int face[6]; bool open; };
+        std::vector<BoxCand> cands;
+        auto take = [&](float x0, float x1, float y0, float y1, float z0, float z1, const int face[6], bool open) {
+          BoxCand c{{x0, x1, y0, y1, z0, z1}, {face[0], face[1], face[2], face[3], face[4], face[5]}, open};
+          for (int i : c.face)
+            if (i >= 0) used(i) = 1;
+          cands.push_back(c);
+        };
         for (int p = o_xy; p < o_xz; ++p) {
           for (int q = p + 1; q < o_xz && !used(p); ++q) {
             if (used(q) || !same_face(p, q) || F5(p)[4] == F5(q)[4]) continue;
@@ -648,22 +655,14 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
             int fy[2], fx[2];
             if (!find_pair(o_xz, o_yz, x0, x1, z0, z1, y0, y1, fy)) continue;
             if (!find_pair(o_yz, o_end, y0, y1, z0, z1, x0, x1, fx)) continue;
-            const int fz[2] = {F5(p)[4] == z0 ? p : q, F5(p)[4] == z0 ? q : p};
-            for (float v : {x0, x1, y0, y1, z0, z1}) brute_boxes.push_back(v);
-            for (int i : {fz[0], fz[1], fy[0], fy[1], fx[0], fx[1]}) {
-              float bits;
-              std::memcpy(&bits, &i, 4);
-              brute_boxes.push_back(bits);
-              used(i) = 1;
-            }
-            ++n_box;
+            const int face[6] = {F5(p)[4] == z0 ? p : q, F5(p)[4] == z0 ? q : p, fy[0], fy[1], fx[0], fx[1]};
+            take(x0, x1, y0, y1, z0, z1, face, false);
           }
         }
-        // Five (or six, of several materials) rects that are faces of ONE axis-aligned box, the room of
-        // the Cornell worlds (scenes.clj:76-81): the same slab test with the missing face marked -1.
-        // Every XY rect left is tried as a z face; the z extent comes from an XZ or YZ rect that
-        // spans the XY rect's x or y extent and starts or ends on its plane.
-        int n_open = 0;
+        // Five rects that are faces of ONE axis-aligned box, the room of the Cornell worlds
+        // (scenes.clj:76-81), whatever their materials: the same slab test with the missing face
+        // marked -1. Every XY rect left is tried as a z face; the z extent comes from an XZ or YZ
+        // rect that spans the XY rect's x or y extent and starts or ends on its plane.
         for (int p = o_xy; p < o_xz; ++p) {
           if (used(p)) continue;
           const float x0 = F5(p)[0], x1 = F5(p)[1], y0 = F5(p)[2], y1 = F5(p)[3], kz = F5(p)[4];
@@ -697,16 +696,48 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
             int n_faces = 0;
             for (int i : face) n_faces += i >= 0;
             if (n_faces != 5) continue;
-            for (float v : {x0, x1, y0, y1, z0, z1}) brute_boxes.push_back(v);
-            for (int i : face) {
-              float bits;
-              std::memcpy(&bits, &i, 4);
-              brute_boxes.push_back(bits);
-              if (i >= 0) used(i) = 1;
-            }
-            ++n_open;
+            take(x0, x1, y0, y1, z0, z1, face, true);
             break;
           }
+        }
+        // The device tests loose rects first, then the closed boxes, then the open ones. That differs from
+        // the scan only where two rects can tie: same orientation, same plane, overlapping. The later
+        // one in the scan must win (rectangles.clj accepts t = t-max), so the earlier one has to be tested
+        // first; a box whose face would be tested AFTER a coinciding later rect is given up (its rects
+        // go back to the loose ones, which are tested in scan order and before every box).
+        auto coincide = [&](int i, int j) {
+          const float *a = F5(i), *b = F5(j);
+          return a[4] == b[4] && a[0] < b[1] && b[0] < a[1] && a[2] < b[3] && b[2] < a[3];
+        };
+        for (bool changed = true; changed;) {
+          changed = false;
+          std::stable_partition(cands.begin(), cands.end(), [](const BoxCand& c) { return !c.open; });
+          std::vector<int> place((size_t)(o_end - G.first_prim), 0);  // 0 loose, 1 + index of its box
+          for (size_t c = 0; c < cands.size(); ++c)
+            for (int i : cands[c].face)
+              if (i >= 0) place[(size_t)(i - G.first_prim)] = 1 + (int)c;
+          const int lo[3] = {o_xy, o_xz, o_yz}, hi[3] = {o_xz, o_yz, o_end};
+          for (int t = 0; t < 3 && !changed; ++t)
+            for (int i = lo[t]; i < hi[t] && !changed; ++i)
+              for (int j = i + 1; j < hi[t] && !changed; ++j) {
+                const int pi_ = place[(size_t)(i - G.first_prim)], pj = place[(size_t)(j - G.first_prim)];
+                if (pi_ > pj && coincide(i, j)) {  // i is earlier in the scan and would be tested later
+                  for (int f : cands[(size_t)pi_ - 1].face)
+                    if (f >= 0) used(f) = 0;
+                  cands.erase(cands.begin() + (pi_ - 1));
+                  changed = true;
+                }
+              }
+        }
+        int n_box = 0, n_open = 0;
+        for (const BoxCand& c : cands) {
+          for (float v : c.bounds) brute_boxes.push_back(v);
+          for (int i : c.face) {
+            float bits;
+            std::memcpy(&bits, &i, 4);
+            brute_boxes.push_back(bits);
+          }
+          (c.open ? n_open : n_box) += 1;
         }
         G.flags |= n_open << DGROUP_OPEN_SHIFT;
         // pair records per orientation (see DScene.brute_rects) for the rects no box took

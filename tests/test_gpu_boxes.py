@@ -219,3 +219,75 @@ def test_medium_with_a_general_boundary(gpu_ctx, oracle):
     assert np.array_equal(acc.reshape(H, W, 3), rgb)
     assert st["samples"] == W * H * 4
     sc.close()
+
+
+def _lattice_world(rng):
+    """Rects on a coarse lattice, so that extents coincide by chance: complete boxes, boxes with one, two or
+    three faces missing, boxes of several materials, walls shared between neighbours, duplicates; plus blocks
+    under chains and a few spheres. The host has to find the (open) boxes among them without ever
+    changing an answer."""
+    mats = [RED, GREEN, WHITE]
+    world = []
+    for _ in range(int(rng.integers(2, 6))):
+        p0 = rng.integers(-3, 3, 3) * 4.0
+        size = rng.integers(1, 4, 3) * 4.0
+        p1 = p0 + size
+        faces = [xy_rect(p0[0], p1[0], p0[1], p1[1], p0[2], mats[int(rng.integers(3))]),
+                 xy_rect(p0[0], p1[0], p0[1], p1[1], p1[2], mats[int(rng.integers(3))]),
+                 xz_rect(p0[0], p1[0], p0[2], p1[2], p0[1], mats[int(rng.integers(3))]),
+                 xz_rect(p0[0], p1[0], p0[2], p1[2], p1[1], mats[int(rng.integers(3))]),
+                 yz_rect(p0[1], p1[1], p0[2], p1[2], p0[0], mats[int(rng.integers(3))]),
+                 yz_rect(p0[1], p1[1], p0[2], p1[2], p1[0], mats[int(rng.integers(3))])]
+        keep = rng.permutation(6)[: int(rng.integers(3, 7))]
+        world += [faces[i] for i in sorted(keep, key=lambda _: rng.random())]
+        if rng.random() < 0.3:
+            world.append(faces[int(keep[0])])      # a duplicate wall
+    for _ in range(int(rng.integers(0, 3))):
+        b = box([0, 0, 0], list(rng.integers(1, 4, 3) * 2.0), mats[int(rng.integers(3))])
+        world.append(translate(rotate_y(b, float(rng.uniform(-60, 60))), list(rng.uniform(-8, 8, 3))))
+    from raytracing_amd.hittables import sphere
+    for _ in range(int(rng.integers(0, 3))):
+        world.append(sphere(list(rng.uniform(-10, 10, 3)), float(rng.uniform(0.5, 3)), mats[int(rng.integers(3))]))
+    order = rng.permutation(len(world))
+    return [world[i] for i in order]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_lattice_worlds_against_the_oracle(gpu_ctx, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    flat = flatten.flatten_world(_lattice_world(rng))
+    sc = gpu_ctx.scene(flat)
+    n = 6000
+    o = rng.uniform(-14, 14, (n, 3)).astype(np.float32)
+    d = (rng.uniform(-10, 10, (n, 3)) - o).astype(np.float32)       # towards the middle, where the walls are
+    dev = sc.hit_batch(o, d)
+    orc = oracle.hit_batch(flat, o, d)
+    assert int(orc[:, 11].sum()) > n // 20
+    _check_hits(dev, orc, o, d, 2e-4)
+    rv, cover = sc.variants()
+    for v in cover:                                    # every instantiation that covers the world agrees bit for bit
+        assert sc.hit_batch(o, d, variant=v).tobytes() == dev.tobytes()
+    sc.close()
+
+
+def test_a_rect_that_coincides_with_a_box_face_wins_when_it_comes_later(gpu_ctx, oracle):
+    """rectangles.clj accepts t = t-max, so of two coinciding rects the LATER one in the scan wins. The
+    device tests loose rects before boxes: a box (or room) whose face coincides with a later loose rect is
+    therefore not merged. All four orders, exact rays."""
+    room = [xy_rect(0, 4, 0, 4, 4, WHITE), xz_rect(0, 4, 0, 4, 0, WHITE), xz_rect(0, 4, 0, 4, 4, WHITE),
+            yz_rect(0, 4, 0, 4, 0, WHITE), yz_rect(0, 4, 0, 4, 4, WHITE)]
+    patch = xy_rect(1, 3, 1, 3, 4, GREEN)
+    worlds = {"box then rect": [box([0, 0, 0], [4, 4, 4], WHITE), xy_rect(0, 4, 0, 4, 4, GREEN)],
+              "rect then box": [xy_rect(0, 4, 0, 4, 4, GREEN), box([0, 0, 0], [4, 4, 4], WHITE)],
+              "room then rect": room + [patch], "rect then room": [patch] + room}
+    o = np.float32([[2, 2, 2]] * 4)
+    d = np.float32([[0, 0, 1], [0.1, 0.05, 1], [0.2, -0.1, 1], [-0.3, 0.2, 1]])
+    for name, world in worlds.items():
+        flat = flatten.flatten_world(world)
+        sc = gpu_ctx.scene(flat)
+        dev = sc.hit_batch(o, d)
+        orc = oracle.hit_batch(flat, o, d)
+        assert dev["hit"].all() and orc[:, 11].all(), name
+        assert np.array_equal(dev["mat_id"], orc[:, 10].astype(np.int32)), name
+        assert np.array_equal(dev["t"], orc[:, 0].astype(np.float32)), name
+        sc.close()
