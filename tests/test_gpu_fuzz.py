@@ -1,0 +1,173 @@
+"""Random worlds out of everything the path knows — spheres, moving spheres, rects, boxes, lists, rotate-y
+and translate wrappers nested up to three deep, constant media with sphere, box and list boundaries,
+all five materials, checker / noise / image textures — against the oracle: closest-hit records (with scripted
+medium uniforms) and per-sample radiance with the shared random stream, on every kernel instantiation that
+covers the world. The fixed worlds of the other tests were written with the device's fast paths in mind;
+these are not."""
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, flatten
+from raytracing_amd.core import build_camera
+from raytracing_amd.hittables import (box, constant_medium, hittable_list, moving_sphere, rotate_y, sphere, translate,
+                                      xy_rect, xz_rect, yz_rect)
+from raytracing_amd.materials import Metal, dielectric, diffuse_light, lambertian, metal
+from raytracing_amd.texture import checker_texture, image_texture, noise_texture, resource, solid_color
+from test_gpu_parity import _check_hits
+
+pytestmark = pytest.mark.gpu
+
+
+class _PyRng:  # the two calls texture.perlin makes
+    def __init__(self, seed):
+        self.r = np.random.default_rng(seed)
+
+    def random(self):
+        return float(self.r.random())
+
+    def shuffle(self, x):
+        self.r.shuffle(x)
+
+
+PROFILES = {  # what a world may contain -> the instantiation it should land on
+    "any": None,
+    "rect": dict(shapes=(2, 3, 4, 5), mats=(0, 8), wrap=3, media=(1,), want=("V_RECT", "V_SMOKE")),
+    "list": dict(shapes=(0, 1, 2, 3, 4), mats=(0, 5, 6, 7, 8, 9, 10), wrap=0, media=(), want=("V_LIST", "V_SPH")),
+    "noise": dict(shapes=(0, 2, 3, 4), mats=(0, 8, 9, 11), wrap=0, media=(), want=("V_NOISE", "V_LIST")),
+}
+
+
+def _material(rng, textures, allowed=None):
+    k = int(rng.integers(0, 10)) if allowed is None else int(allowed[int(rng.integers(len(allowed)))])
+    if k == 10:
+        return lambertian(textures[1])      # the image
+    if k == 11:
+        return lambertian(textures[0])      # noise
+    col = [float(c) for c in rng.uniform(0.1, 0.9, 3)]
+    if k <= 3:
+        return lambertian(col)
+    if k == 4:
+        return lambertian(textures[int(rng.integers(len(textures)))])
+    if k == 5:
+        return metal(col, float(rng.uniform(0, 0.6)))
+    if k == 6:
+        return Metal(col, float(rng.uniform(0, 1.5)))       # the record constructor does not clamp the fuzz
+    if k == 7:
+        return dielectric(float(rng.uniform(1.1, 2.0)))
+    if k == 8:
+        return diffuse_light([float(c) for c in rng.uniform(1, 6, 3)])
+    return lambertian(checker_texture(col, [0.9, 0.9, 0.9]))
+
+
+def _shape(rng, mat, extent, allowed=None):
+    k = int(rng.integers(0, 7)) if allowed is None else int(allowed[int(rng.integers(len(allowed)))])
+    c = rng.uniform(-extent, extent, 3)
+    if k == 0:
+        return sphere(list(c), float(rng.uniform(0.3, 2.5)), mat)
+    if k == 1:
+        return moving_sphere(list(c), list(c + rng.uniform(-1, 1, 3)), 0.0, 1.0, float(rng.uniform(0.3, 1.5)), mat)
+    if k in (2, 3, 4):
+        a0, b0 = c[0], c[1]
+        a1, b1 = a0 + rng.uniform(0.5, 6), b0 + rng.uniform(0.5, 6)
+        return (xy_rect, xz_rect, yz_rect)[k - 2](a0, a1, b0, b1, float(c[2]), mat)     # `^long k` truncates c[2]
+    if k == 5:
+        return box(list(c), list(c + rng.uniform(0.5, 4, 3)), mat)
+    return hittable_list([_shape(rng, mat, extent) for _ in range(int(rng.integers(2, 4)))])
+
+
+def _wrapped(rng, obj, depth):
+    for _ in range(depth):
+        if rng.random() < 0.5:
+            obj = translate(obj, [float(v) for v in rng.uniform(-3, 3, 3)])
+        else:
+            obj = rotate_y(obj, float(rng.uniform(-80, 80)))
+    return obj
+
+
+def _world(rng, n_objects, extent, profile=None):
+    textures = [noise_texture(_PyRng(int(rng.integers(1 << 30))), float(rng.uniform(1, 6))),
+                image_texture(resource("stones.jpg")),
+                checker_texture(noise_texture(_PyRng(int(rng.integers(1 << 30))), 3.0), solid_color(0.2, 0.3, 0.1))]
+    world = []
+    for _ in range(n_objects):
+        if profile is None:
+            obj = _wrapped(rng, _shape(rng, _material(rng, textures), extent), int(rng.integers(0, 4)))
+        else:
+            obj = _wrapped(rng, _shape(rng, _material(rng, textures, profile["mats"]), extent, profile["shapes"]),
+                           int(rng.integers(0, profile["wrap"] + 1)))
+        if rng.random() < 0.12 and (profile is None or profile["media"]):
+            kind = int(rng.integers(0, 3)) if profile is None else int(profile["media"][0])
+            c = rng.uniform(-extent, extent, 3)
+            if kind == 0:
+                b = sphere(list(c), float(rng.uniform(1, 4)), lambertian([0.5, 0.5, 0.5]))
+            elif kind == 1:
+                if profile is not None:     # whole coordinates: `^long k` then leaves the six rects a closed box
+                    c = np.round(c)
+                    b = box(list(c), list(c + rng.integers(1, 5, 3)), lambertian([0.5, 0.5, 0.5]))
+                else:
+                    b = box(list(c), list(c + rng.uniform(1, 5, 3)), lambertian([0.5, 0.5, 0.5]))
+            else:
+                b = hittable_list([sphere(list(c), 2.0, lambertian([0.5, 0.5, 0.5])),
+                                   box(list(c), list(c + 2.5), lambertian([0.5, 0.5, 0.5]))])
+            obj = constant_medium(_wrapped(rng, b, int(rng.integers(0, 3))), float(rng.uniform(0.05, 0.8)),
+                                  [float(v) for v in rng.uniform(0.1, 0.9, 3)])
+        world.append(obj)
+    world.append(xz_rect(-3 * extent, 3 * extent, -3 * extent, 3 * extent, -extent - 1, lambertian([0.5, 0.6, 0.5])))
+    return world
+
+
+CASES = [("any", s, n) for s, n in zip(range(16), [4, 6, 9, 12, 14, 20, 30, 45, 5, 8, 60, 16, 25, 7, 90, 11])]
+CASES += [("rect", 20 + s, n) for s, n in zip(range(6), [3, 5, 8, 4, 6, 10])]
+CASES += [("list", 30 + s, n) for s, n in zip(range(8), [3, 6, 10, 14, 30, 80, 200, 12])]
+CASES += [("noise", 40 + s, n) for s, n in zip(range(5), [2, 4, 8, 12, 15])]
+
+
+@pytest.mark.parametrize("profile,seed,n_objects", CASES)
+def test_random_world(gpu_ctx, oracle, profile, seed, n_objects):
+    rng = np.random.default_rng(7000 + seed)
+    extent = 6.0 + 0.15 * min(n_objects, 100)
+    flat = flatten.flatten_world(_world(rng, n_objects, extent, PROFILES[profile]))
+    sc = gpu_ctx.scene(flat)
+    rv, cover = sc.variants()
+    if PROFILES[profile]:
+        assert abi.VARIANT_NAMES[rv] in PROFILES[profile]["want"], abi.VARIANT_NAMES[rv]
+    nm = flat.desc.n_media
+    n = 8000
+    o = rng.uniform(-1.6 * extent, 1.6 * extent, (n, 3)).astype(np.float32)
+    d = (rng.uniform(-extent, extent, (n, 3)) - o).astype(np.float32)
+    d[: n // 4] = rng.normal(size=(n // 4, 3)).astype(np.float32)
+    tm = rng.random(n).astype(np.float32)
+    xi = rng.random((n, nm)).astype(np.float32) if nm else None
+    dev = sc.hit_batch(o, d, tm, medium_xi=xi)
+    orc = oracle.hit_batch(flat, o, d, tm, medium_xi=xi)
+    assert int(orc[:, 11].sum()) > n // 10
+    _check_hits(dev, orc, o, d, 3e-4, label=f"random world {seed} ({n_objects} objects, {flat.desc.n_prims} primitives, "
+                                             f"{nm} media, renders on {abi.VARIANT_NAMES[rv]})")
+    for v in cover:
+        assert sc.hit_batch(o, d, tm, medium_xi=xi, variant=v).tobytes() == dev.tobytes(), abi.VARIANT_NAMES[v]
+    # per-sample radiance through the instantiation the render uses
+    cfg = {"lookfrom": [0.0, 0.6 * extent, -2.2 * extent], "lookat": [0.0, 0.0, 0.0], "vfov": 50.0, "aperture": 0.1,
+           "background": [0.5, 0.6, 0.8]}
+    cam = build_camera(cfg, 1.0)
+    W = H = 48
+    p = abi.make_params(W, H, 4, 50, cfg["background"], seed=11 + seed)
+    m = 3000
+    px = rng.integers(0, W * H, m).astype(np.int32)
+    smp = rng.integers(0, 2000, m).astype(np.int32)
+    a = sc.sample_batch(cam, p, px, smp)
+    b = oracle.sample_batch(flat, cam, p, px, smp)
+    rel = np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-2)
+    diverged = int((rel > 2e-3).sum())
+    print(f"[parity] random world {seed} per-sample radiance: {diverged} of {m} diverged, median {np.median(rel):.2e}")
+    assert diverged <= max(3, int(3e-3 * m)) and np.median(rel) <= 2e-5
+    # and a small frame equals the ordered sum of its samples
+    q = abi.make_params(24, 24, 3, 50, cfg["background"], seed=11 + seed)
+    rgb, _, st = sc.render(cam, q)
+    px2 = np.repeat(np.arange(24 * 24, dtype=np.int32), 3)
+    smp2 = np.tile(np.arange(3, dtype=np.int32), 24 * 24)
+    s = sc.sample_batch(cam, q, px2, smp2).reshape(24 * 24, 3, 3).astype(np.float32)
+    want = np.zeros((24 * 24, 3), np.float32)
+    for k in range(3):
+        want = want + s[:, k, :]
+    assert np.array_equal(rgb.astype(np.float32).reshape(-1, 3).view(np.uint32), want.view(np.uint32))
+    sc.close()
