@@ -170,4 +170,17 @@ def test_random_world(gpu_ctx, oracle, profile, seed, n_objects):
     for k in range(3):
         want = want + s[:, k, :]
     assert np.array_equal(rgb.astype(np.float32).reshape(-1, 3).view(np.uint32), want.view(np.uint32))
+    # the same frame from the kernel that re-packs paths (where the world can use it; ignored elsewhere), from two
+    # tile shards added up, and from the world written to a scene file and read back
+    bits = rgb.view(np.uint32)
+    pool, _, st2 = sc.render(cam, abi.make_params(24, 24, 3, 50, cfg["background"], seed=11 + seed, flags=abi.RT_FLAG_POOL_PATHS))
+    assert np.array_equal(pool.view(np.uint32), bits) and st2["rays"] == st["rays"]
+    halves = [sc.render(cam, abi.make_params(24, 24, 3, 50, cfg["background"], seed=11 + seed, shard_index=k, shard_count=2))[0]
+              for k in (0, 1)]
+    assert np.array_equal((halves[0] + halves[1]).view(np.uint32), bits)
+    from raytracing_amd import scenefile
+    again = gpu_ctx.scene_from_bytes(scenefile.dumps(flat))
+    assert np.array_equal(again.render(cam, q)[0].view(np.uint32), bits)
+    assert again.hit_batch(o, d, tm, medium_xi=xi).tobytes() == dev.tobytes()
+    again.close()
     sc.close()
