@@ -193,8 +193,12 @@ constexpr int waves_per_simd(uint32_t feat, bool count) {
 #ifndef RT_WAVE_DRAW_SPH
 #define RT_WAVE_DRAW_SPH 0
 #endif
+#ifndef RT_WAVE_DRAW_LIST
+#define RT_WAVE_DRAW_LIST 0
+#endif
 constexpr bool wave_draw(uint32_t feat) {
   if (feat & F_SMALL) return true;
+  if ((feat & F_SPHERES) && !(feat & (F_BVH | F_NOISE | F_MEDIA | F_CHAINS))) return RT_WAVE_DRAW_LIST != 0;
   if (feat & F_NOISE) return (feat & F_DEEP) ? RT_WAVE_DRAW_DEEP != 0 : RT_WAVE_DRAW_ALL != 0;
   return RT_WAVE_DRAW_SPH != 0;
 }
