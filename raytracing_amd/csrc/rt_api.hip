@@ -206,6 +206,7 @@ struct Sink {  // leaves reached under each chain, in scan order, duplicates dro
   std::vector<int> chain_order;
   std::map<int, std::vector<int>> prims;
   std::set<std::pair<int, int>> seen;
+  std::set<std::pair<int, int>> walked;  // (node, chain) already expanded into this sink
   void add(int chain, int prim) {
     if (!seen.insert({chain, prim}).second) return;
     if (!prims.count(chain)) chain_order.push_back(chain);
@@ -220,6 +221,7 @@ struct HostMedium {
   bool present = false;
 };
 
+#define RT_MAX_TREE_DEPTH 2048
 struct Flattener {
   const rt_scene_desc* d;
   std::vector<std::vector<DChainOp>> chains{{}};  // chain 0 = identity
@@ -237,9 +239,15 @@ struct Flattener {
     return (int)chains.size() - 1;
   }
 
-  void walk(int node, int chain, Sink& sink, bool in_boundary) {
+  // A subtree reached a second time under the same chain adds nothing (its leaves are already in the
+  // sink, in the place of their first occurrence), so it is not expanded again: a description that
+  // shares subtrees (the reference's bvhnode does, base.clj:143-160) costs what it holds, not what it
+  // unfolds to. Depth is bounded because the walk recurses on the host stack.
+  void walk(int node, int chain, Sink& sink, bool in_boundary, int depth = 0) {
     if (err) return;
     if (on_stack[node]) { err = fail(RT_ERR_ARG, "node %d: the hittable tree has a cycle", node); return; }
+    if (depth > RT_MAX_TREE_DEPTH) { err = fail(RT_ERR_UNSUPPORTED, "the hittable tree is more than %d levels deep", RT_MAX_TREE_DEPTH); return; }
+    if (!sink.walked.insert({node, chain}).second) return;
     on_stack[node] = 1;
     const int32_t* ni = d->node_i + (size_t)node * RT_NODE_ISTRIDE;
     const double* nd = d->node_d + (size_t)node * RT_NODE_DSTRIDE;
@@ -248,11 +256,11 @@ struct Flattener {
         sink.add(chain, ni[0]);
         break;
       case RT_NODE_LIST:
-        for (int c = 0; c < ni[1] && !err; ++c) walk(d->node_children[ni[0] + c], chain, sink, in_boundary);
+        for (int c = 0; c < ni[1] && !err; ++c) walk(d->node_children[ni[0] + c], chain, sink, in_boundary, depth + 1);
         break;
       case RT_NODE_BVH:
-        walk(ni[0], chain, sink, in_boundary);
-        walk(ni[1], chain, sink, in_boundary);
+        walk(ni[0], chain, sink, in_boundary, depth + 1);
+        walk(ni[1], chain, sink, in_boundary, depth + 1);
         break;
       case RT_NODE_TRANSLATE:
       case RT_NODE_ROTATE_Y: {
@@ -267,7 +275,7 @@ struct Flattener {
         op.da = nd[0]; op.db = nd[1]; op.dc = op.kind == DOP_TRANSLATE ? nd[2] : 0.0;
         op.a = (float)op.da; op.b = (float)op.db; op.c = (float)op.dc;
         ops.push_back(op);
-        walk(ni[0], intern(ops), sink, in_boundary);
+        walk(ni[0], intern(ops), sink, in_boundary, depth + 1);
         break;
       }
       case RT_NODE_MEDIUM: {
@@ -280,7 +288,7 @@ struct Flattener {
         M.outer_chain = chain;
         M.phase_mat = ni[1];
         M.neg_inv_density = (float)nd[0];
-        walk(ni[0], chain, M.boundary, true);
+        walk(ni[0], chain, M.boundary, true, depth + 1);
         break;
       }
     }

@@ -113,3 +113,39 @@ def test_duplicate_spheres(gpu_ctx, oracle):
     assert int((orc[:, 11] > 0.5).sum()) > n // 4
     _check_hits(dev, orc, o, d, 1e-4)
     sc.close()
+
+
+def _chain_of_nodes(kind, depth):
+    """A sphere below `depth` nested nodes built straight into the description (the Python flattener would
+    recurse as deep): kind LIST holds one child each, kind BVH names the same child twice."""
+    fs = flatten.flatten_world([sphere([0, 0, -5], 1, GREY)])
+    top = next(i for i, k in enumerate(fs.node_kind) if k == abi.RT_NODE_PRIM)
+    for _ in range(depth):
+        if kind == abi.RT_NODE_LIST:
+            fs.node_i.append([len(fs.node_children), 1, 0, 0])
+            fs.node_children.append(top)
+        else:
+            fs.node_i.append([top, top, 0, 0])
+        fs.node_kind.append(kind)
+        fs.node_d.append([0.0] * abi.RT_NODE_DSTRIDE)
+        top = len(fs.node_kind) - 1
+    fs.root = top
+    return fs.finish()
+
+
+def test_shared_subtrees_cost_what_they_hold_and_depth_is_bounded(gpu_ctx):
+    """A tree whose every level names its child twice unfolds to 2^64 leaves and holds one: it is created
+    at once and answers like the sphere it is. A tree 100 000 levels deep is refused, not walked into a
+    stack overflow."""
+    flat = _chain_of_nodes(abi.RT_NODE_BVH, 64)
+    sc = gpu_ctx.scene(flat)
+    assert sc.info()["n_prims_flat"] == 1
+    h = sc.hit_batch(np.float32([[0, 0, 0]]), np.float32([[0, 0, -1]]))
+    assert h["hit"][0] == 1 and abs(float(h["t"][0]) - 4.0) < 1e-6
+    sc.close()
+    ok = gpu_ctx.scene(_chain_of_nodes(abi.RT_NODE_LIST, 1500))
+    assert ok.info()["n_prims_flat"] == 1
+    ok.close()
+    with pytest.raises(lib.RtError) as ei:
+        gpu_ctx.scene(_chain_of_nodes(abi.RT_NODE_LIST, 100000))
+    assert ei.value.code == abi.RT_ERR_UNSUPPORTED and "deep" in str(ei.value)

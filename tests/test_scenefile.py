@@ -132,3 +132,43 @@ def test_library_rejects_malformed_scene_files(tmp_path):
     assert rc == 0 and h
     L.rt_scene_destroy(h)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell-smoke", "two-perlin-spheres", "random-scene"])
+def test_mutated_scene_files_never_take_the_library_down(name):
+    """Scene files are untrusted input: a few hundred copies of a valid file with one to four bytes
+    overwritten (random values and the usual suspects: 0x00, 0xff, 0x7f, 0x80) are either refused with a code
+    or load as SOME world, which then answers closest-hit queries and renders a few pixels."""
+    cfg, flat = setup(name, 2)
+    cam = build_camera(cfg, 1.0)
+    data = bytearray(scenefile.dumps(flat))
+    rng = np.random.default_rng(99)
+    ctx = lib.Context(0)
+    o = rng.uniform(-20, 20, (64, 3)).astype(np.float32)
+    d = rng.normal(size=(64, 3)).astype(np.float32)
+    tm = rng.random(64).astype(np.float32)
+    loaded = refused = 0
+    for trial in range(250):
+        blob = bytearray(data)
+        # most of the mutations go where the structure is: the header and the index arrays behind it
+        span = len(blob) if trial % 3 == 0 else min(len(blob), 4096)
+        at = int(rng.integers(8, span))
+        width = int(rng.integers(1, 5))
+        fill = [rng.integers(0, 256, width).astype(np.uint8).tobytes(), b"\x00" * width, b"\xff" * width,
+                b"\x7f" * width, b"\x80" * width][int(rng.integers(0, 5))]
+        blob[at:at + width] = fill[: max(0, min(width, len(blob) - at))]
+        try:
+            sc = ctx.scene_from_bytes(bytes(blob))
+        except lib.RtError as e:
+            assert e.code in (abi.RT_ERR_ARG, abi.RT_ERR_UNSUPPORTED), (trial, e)
+            refused += 1
+            continue
+        loaded += 1
+        nm = sc.info()["n_media"]
+        xi = rng.random((64, nm)).astype(np.float32) if nm else None
+        sc.hit_batch(o, d, tm, medium_xi=xi)
+        sc.render(cam, abi.make_params(8, 8, 1, 6, cfg["background"], seed=trial))
+        sc.close()
+    assert loaded > 20 and refused > 20, (loaded, refused)
+    ctx.close()
