@@ -34,6 +34,8 @@ PROFILES = {  # what a world may contain -> the instantiation it should land on
     "rect": dict(shapes=(2, 3, 4, 5), mats=(0, 8), wrap=3, media=(1,), want=("V_RECT", "V_SMOKE")),
     "list": dict(shapes=(0, 1, 2, 3, 4), mats=(0, 5, 6, 7, 8, 9, 10), wrap=0, media=(), want=("V_LIST", "V_SPH")),
     "noise": dict(shapes=(0, 2, 3, 4), mats=(0, 8, 9, 11), wrap=0, media=(), want=("V_NOISE", "V_LIST")),
+    # big lists below wrappers: trees under instance chains (spheres there take the FP64 ray transform)
+    "instanced": dict(shapes=(0, 1, 2, 3, 4, 5), mats=None, wrap=3, media=(0, 1), want=None, lists=(18, 70)),
 }
 
 
@@ -92,16 +94,20 @@ def _world(rng, n_objects, extent, profile=None):
     for _ in range(n_objects):
         if profile is None:
             obj = _wrapped(rng, _shape(rng, _material(rng, textures), extent), int(rng.integers(0, 4)))
+        elif "lists" in profile:
+            members = [_shape(rng, _material(rng, textures), extent, profile["shapes"])
+                       for _ in range(int(rng.integers(*profile["lists"])))]
+            obj = _wrapped(rng, hittable_list(members), int(rng.integers(1, profile["wrap"] + 1)))
         else:
             obj = _wrapped(rng, _shape(rng, _material(rng, textures, profile["mats"]), extent, profile["shapes"]),
                            int(rng.integers(0, profile["wrap"] + 1)))
         if rng.random() < 0.12 and (profile is None or profile["media"]):
-            kind = int(rng.integers(0, 3)) if profile is None else int(profile["media"][0])
+            kind = int(rng.integers(0, 3)) if profile is None else int(profile["media"][int(rng.integers(len(profile["media"])))])
             c = rng.uniform(-extent, extent, 3)
             if kind == 0:
                 b = sphere(list(c), float(rng.uniform(1, 4)), lambertian([0.5, 0.5, 0.5]))
             elif kind == 1:
-                if profile is not None:     # whole coordinates: `^long k` then leaves the six rects a closed box
+                if profile is not None and "lists" not in profile:     # whole coordinates: `^long k` then leaves the six rects a closed box
                     c = np.round(c)
                     b = box(list(c), list(c + rng.integers(1, 5, 3)), lambertian([0.5, 0.5, 0.5]))
                 else:
@@ -120,6 +126,7 @@ CASES = [("any", s, n) for s, n in zip(range(16), [4, 6, 9, 12, 14, 20, 30, 45, 
 CASES += [("rect", 20 + s, n) for s, n in zip(range(6), [3, 5, 8, 4, 6, 10])]
 CASES += [("list", 30 + s, n) for s, n in zip(range(8), [3, 6, 10, 14, 30, 80, 200, 12])]
 CASES += [("noise", 40 + s, n) for s, n in zip(range(5), [2, 4, 8, 12, 15])]
+CASES += [("instanced", 50 + s, n) for s, n in zip(range(6), [2, 2, 3, 4, 6, 9])]
 
 
 @pytest.mark.parametrize("profile,seed,n_objects", CASES)
@@ -129,7 +136,7 @@ def test_random_world(gpu_ctx, oracle, profile, seed, n_objects):
     flat = flatten.flatten_world(_world(rng, n_objects, extent, PROFILES[profile]))
     sc = gpu_ctx.scene(flat)
     rv, cover = sc.variants()
-    if PROFILES[profile]:
+    if PROFILES[profile] and PROFILES[profile]["want"]:
         assert abi.VARIANT_NAMES[rv] in PROFILES[profile]["want"], abi.VARIANT_NAMES[rv]
     nm = flat.desc.n_media
     n = 8000
