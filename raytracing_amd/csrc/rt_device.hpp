@@ -515,37 +515,40 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
 #ifdef RT_STAMPS
   unsigned long long st_a, st_b, st_c;
 #endif
+  // one step of the walk from the two quarters of a node record
+  auto step = [&](const u4 q0, const u4 q1) {
+    // halves in storage order: left centre xyz, left half-extent xyz, right centre xyz, right half-extent xyz
+    // (plain scalars first: a bit cast applied to a vector element reads the vector's first one)
+    const uint32_t w0 = q0.x, w1 = q0.y, w2 = q0.z, w3 = q0.w, w4 = q1.x, w5 = q1.y;
+    const h2 a0 = __builtin_bit_cast(h2, w0), a1 = __builtin_bit_cast(h2, w1), a2 = __builtin_bit_cast(h2, w2);
+    const h2 a3 = __builtin_bit_cast(h2, w3), a4 = __builtin_bit_cast(h2, w4), a5 = __builtin_bit_cast(h2, w5);
+    const int left = (int)q1.z, right = (int)q1.w;
+    float tl, tr;
+    tally.template add<RT_EV_AABB_TEST>(2);
+    const bool hl = slab16(a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, inv, oi, tmin, best.t, tl);
+    const bool hr = slab16(a3.x, a3.y, a4.x, a4.y, a5.x, a5.y, inv, oi, tmin, best.t, tr);
+    if (hl && hr) {
+      const bool swap = tr < tl;
+      ctx.lds_stack[sp] = swap ? left : right;
+      sp += stride;
+      node = swap ? right : left;
+    } else if (hl || hr) {
+      node = hl ? left : right;
+    } else if (sp > 0) {
+      sp -= stride;
+      node = ctx.lds_stack[sp];
+    } else {
+      node = RT_BVH_DONE;
+    }
+  };
+  // The root is the same record for every lane: its step reads it through the scalar cache (the index is
+  // wave-uniform), one vector-memory round trip less per walk.
+  step(nodes4[root * 2 + 0], nodes4[root * 2 + 1]);
   while (node != RT_BVH_DONE) {
 #ifdef RT_STAMPS
     __builtin_amdgcn_sched_barrier(0); st_a = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #endif
-    while ((unsigned)node < (unsigned)RT_BVH_DONE) {  // internal
-      const u4 q0 = nodes4[node * 2 + 0];
-      const u4 q1 = nodes4[node * 2 + 1];
-      // halves in storage order: left centre xyz, left half-extent xyz, right centre xyz, right half-extent xyz
-      // (plain scalars first: a bit cast applied to a vector element reads the vector's first one)
-      const uint32_t w0 = q0.x, w1 = q0.y, w2 = q0.z, w3 = q0.w, w4 = q1.x, w5 = q1.y;
-      const h2 a0 = __builtin_bit_cast(h2, w0), a1 = __builtin_bit_cast(h2, w1), a2 = __builtin_bit_cast(h2, w2);
-      const h2 a3 = __builtin_bit_cast(h2, w3), a4 = __builtin_bit_cast(h2, w4), a5 = __builtin_bit_cast(h2, w5);
-      const int left = (int)q1.z, right = (int)q1.w;
-      float tl, tr;
-      tally.template add<RT_EV_AABB_TEST>(2);
-      const bool hl = slab16(a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, inv, oi, tmin, best.t, tl);
-      const bool hr = slab16(a3.x, a3.y, a4.x, a4.y, a5.x, a5.y, inv, oi, tmin, best.t, tr);
-      if (hl && hr) {
-        const bool swap = tr < tl;
-        ctx.lds_stack[sp] = swap ? left : right;
-        sp += stride;
-        node = swap ? right : left;
-      } else if (hl || hr) {
-        node = hl ? left : right;
-      } else if (sp > 0) {
-        sp -= stride;
-        node = ctx.lds_stack[sp];
-      } else {
-        node = RT_BVH_DONE;
-      }
-    }
+    while ((unsigned)node < (unsigned)RT_BVH_DONE) step(nodes4[node * 2 + 0], nodes4[node * 2 + 1]);  // internal
 #ifdef RT_STAMPS
     __builtin_amdgcn_sched_barrier(0); st_b = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #endif
