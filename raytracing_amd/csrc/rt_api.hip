@@ -967,6 +967,8 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
     HIPCHK(hipMemset(p, 0, sizeof(DBvhNode) * (size_t)std::max(n_bvh_nodes, 1)));
     d_nodes = static_cast<DBvhNode*>(p);
   }
+  if (n_bvh_nodes && n_real_prims > (size_t)RT_LEAF_INDEX_MASK)
+    return fail(RT_ERR_UNSUPPORTED, "%zu primitives; a world with trees holds at most %d", n_real_prims, RT_LEAF_INDEX_MASK);
   int node_base = 0, max_height = 0;
   for (auto& G : groups) {
     const int n_prims = group_size(G);
@@ -990,7 +992,7 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, sizeof(DBvhNode16) * (size_t)std::max(n_bvh_nodes, 1)));
     sc->allocs.push_back(p);
-    hipError_t e = pack_bvh_nodes(d_nodes, static_cast<DBvhNode16*>(p), n_bvh_nodes, 0);
+    hipError_t e = pack_bvh_nodes(d_nodes, d_prims, static_cast<DBvhNode16*>(p), n_bvh_nodes, 0);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "BVH packing failed: %s", hipGetErrorString(e));
     S.nodes = static_cast<const DBvhNode16*>(p);
   }

@@ -297,7 +297,7 @@ __global__ void k_renumber(const DBvhNode* __restrict__ nodes, DBvhNode* __restr
   out[number[i]] = N;
 }
 
-__global__ void k_pack_nodes(const DBvhNode* __restrict__ nodes, DBvhNode16* __restrict__ packed, int n) {
+__global__ void k_pack_nodes(const DBvhNode* __restrict__ nodes, const DPrim* __restrict__ prims, DBvhNode16* __restrict__ packed, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const DBvhNode N = nodes[i];
@@ -315,15 +315,17 @@ __global__ void k_pack_nodes(const DBvhNode* __restrict__ nodes, DBvhNode16* __r
     pack(N.lmin[a], N.lmax[a], P.lc[a], P.lh[a]);
     pack(N.rmin[a], N.rmax[a], P.rc[a], P.rh[a]);
   }
-  P.left = N.left; P.right = N.right;
+  // leaves: the primitive's type beside its index
+  auto tag = [&](int child) { return child >= 0 ? child : ~(~child | ((prims[~child].type & 15) << RT_LEAF_TYPE_SHIFT)); };
+  P.left = tag(N.left); P.right = tag(N.right);
   packed[i] = P;
 }
 
 }  // namespace
 
-hipError_t pack_bvh_nodes(const DBvhNode* d_nodes, DBvhNode16* d_packed, int n, hipStream_t stream) {
+hipError_t pack_bvh_nodes(const DBvhNode* d_nodes, const DPrim* d_prims, DBvhNode16* d_packed, int n, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_pack_nodes, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, d_packed, n);
+  hipLaunchKernelGGL(k_pack_nodes, dim3((n + 255) / 256), dim3(256), 0, stream, d_nodes, d_prims, d_packed, n);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return hipStreamSynchronize(stream);

@@ -389,11 +389,12 @@ RT_DEV bool wins_tie(int cand_type, int cand_idx, int best_type, int best_idx) {
 }
 
 // One primitive visited OUT of scan order (BVH leaves): explicit tie rule on the ranks.
+// `leaf` is what the tree stores: index | type << RT_LEAF_TYPE_SHIFT.
 template <class X, class T>
-RT_DEV void test_prim_any_order(const DScene& S, int idx, const RayX& r, float tmin, Best& best, T& tally, double tmin64) {
+RT_DEV void test_prim_any_order(const DScene& S, int leaf, const RayX& r, float tmin, Best& best, T& tally, double tmin64) {
   const DPrim RT_CONST* prims = cptr(S.prims);
+  const int idx = leaf & RT_LEAF_INDEX_MASK, type = leaf >> RT_LEAF_TYPE_SHIFT;
   const DPrim RT_CONST& P = prims[idx];
-  const int type = prim_type(P.type);
   float t;
   double root = 0.0;
   if (is_rect(type)) {

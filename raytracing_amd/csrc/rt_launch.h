@@ -59,7 +59,7 @@ hipError_t build_bvh_sah(const DPrim* h_prims, int first, int n, DBvhNode* d_nod
                          float time_hi, int* height, hipStream_t stream);
 
 // Packs n nodes into the 32-byte form the traversal reads (FP16 boxes rounded outwards).
-hipError_t pack_bvh_nodes(const DBvhNode* d_nodes, DBvhNode16* d_packed, int n, hipStream_t stream);
+hipError_t pack_bvh_nodes(const DBvhNode* d_nodes, const DPrim* d_prims, DBvhNode16* d_packed, int n, hipStream_t stream);
 
 }  // namespace rt
 #endif

@@ -89,8 +89,9 @@ struct Pool {
     st(PF_ROOTHI, e, (uint32_t)(bits >> 32));
   }
   // node references on the 16-bit stacks: internal nodes as they are (< 32768), leaves as 0x8000 | primitive
+  // (the type a leaf reference carries beside the index is dropped here and read back from the primitive)
   RT_DEV void push(int e, int level, int ref) const {
-    stack[level * RT_POOL + e] = (uint16_t)(ref >= 0 ? ref : (0x8000 | ~ref));
+    stack[level * RT_POOL + e] = (uint16_t)(ref >= 0 ? ref : (0x8000 | (~ref & RT_LEAF_INDEX_MASK)));
   }
   RT_DEV int pop(int e, int level) const {
     const int r = stack[level * RT_POOL + e];
@@ -425,7 +426,8 @@ __global__ __launch_bounds__(RT_BLOCK, 2) void k_render_pool(RenderArgs A) {
         Best best = Q.best(e);
         const DGroup RT_CONST& G = cptr(S.groups)[g];
         const RayX r = group_ray<Ctx<FEAT>>(S, g, G.flags, G.rc, G.rs, G.bx, G.by, G.bz, wr, tally);
-        test_prim_any_order<Ctx<FEAT>>(S, ~leaf, r, TMIN, best, tally, (double)TMIN);
+        const int lidx = ~leaf & RT_LEAF_INDEX_MASK;
+        test_prim_any_order<Ctx<FEAT>>(S, lidx | (prim_type(cptr(S.prims)[lidx].type) << RT_LEAF_TYPE_SHIFT), r, TMIN, best, tally, (double)TMIN);
         Q.put_best(e, best);
         int node = RT_BVH_DONE;
         if (sp > 0) { sp -= 1; node = Q.pop(e, sp); }

@@ -162,12 +162,16 @@ struct DBvhNode {
 // centre to the nearest half, the half-extent rounded up from what that centre needs to cover both
 // bounds), so a step fetches half as much per lane and the slab test takes its operands straight
 // from the halves (v_fma_mix_f32, nine per box and no min/max to sort near from far). A box can only
-// grow: nothing is culled that the FP32 node would keep.
+// grow: nothing is culled that the FP32 node would keep. A leaf reference carries the primitive's type
+// beside its index (~child = index | RT_PRIM_* << RT_LEAF_TYPE_SHIFT), so the leaf test knows which
+// fields to fetch without reading the primitive's type word first: one memory round trip per leaf, not two.
 struct DBvhNode16 {
   uint16_t lc[3], lh[3];   // left child: centre, half-extent
   uint16_t rc[3], rh[3];   // right child
   int32_t left, right;
 };
+#define RT_LEAF_TYPE_SHIFT 28
+#define RT_LEAF_INDEX_MASK ((1 << RT_LEAF_TYPE_SHIFT) - 1)
 
 struct DMat {
   int32_t type;   // RT_MAT_*
