@@ -907,6 +907,8 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
       texels.push_back((uint32_t)src[3 * t] | ((uint32_t)src[3 * t + 1] << 8) | ((uint32_t)src[3 * t + 2] << 16));
     images[i] = I;
   }
+  for (DTex& T : texs)
+    if (T.type == RT_TEX_IMAGE && T.i0 >= 0) { T.i1 = images[(size_t)T.i0].first_texel; T.w = images[(size_t)T.i0].w; T.h = images[(size_t)T.i0].h; }
 
   // per-primitive record / scatter info (one lookup for the winner of a traversal)
   std::vector<DPrimInfo> infos(prims.size());

@@ -1179,31 +1179,36 @@ template <class X, class T>
 RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, T& tally) {
   const DScene& S = ctx.S;
   const DTex RT_CONST* texs = cptr(S.texs);
-  int type = texs[tex].type;
-  for (int depth = 0; type == RT_TEX_CHECKER && depth < 16; ++depth) {  // :25-30
+  // a texture's whole record in one fetch (its fields are not waited for one after the other)
+  struct TexRec { int type, i0, i1; float r, g, b; int w, h; };
+  auto fetch = [&](int t) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 RT_CONST* q = reinterpret_cast<const u4 RT_CONST*>(texs + t);
+    const u4 a = q[0], b = q[1];
+    return TexRec{(int)a.x, (int)a.y, (int)a.z, __uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y), (int)b.z, (int)b.w};
+  };
+  TexRec R = fetch(tex);
+  for (int depth = 0; R.type == RT_TEX_CHECKER && depth < 16; ++depth) {  // :25-30
     tally.template add<RT_EV_CHECKER>();
     bool nx = sin_negative(10.0 * (double)p.x), ny = sin_negative(10.0 * (double)p.y),
          nz = sin_negative(10.0 * (double)p.z);
     // the product of the three sines is negative iff an odd number of them is, and is +-0 (not
     // negative) when a coordinate is exactly 0
     bool negative = ((nx != ny) != nz) && p.x != 0.0f && p.y != 0.0f && p.z != 0.0f;
-    tex = negative ? texs[tex].i0 : texs[tex].i1;
-    type = texs[tex].type;
+    R = fetch(negative ? R.i0 : R.i1);
   }
-  if (type == RT_TEX_SOLID) return mk(texs[tex].r, texs[tex].g, texs[tex].b);  // :15-17
+  if (R.type == RT_TEX_SOLID) return mk(R.r, R.g, R.b);  // :15-17
   if constexpr (X::has(F_NOISE)) {
-    if (type == RT_TEX_NOISE) {  // :41-44
+    if (R.type == RT_TEX_NOISE) {  // :41-44
       tally.template add<RT_EV_NOISE_TEX>();
-      float k = 0.5f * (1.0f + sinf(fmaf((float)texs[tex].i1, p.z, 10.0f * perlin_turb(ctx, texs[tex].i0, p, 7, tally))));
+      float k = 0.5f * (1.0f + sinf(fmaf((float)R.i1, p.z, 10.0f * perlin_turb(ctx, R.i0, p, 7, tally))));
       return mk(k, k, k);
     }
   }
-  if (X::has(F_IMAGE) && type == RT_TEX_IMAGE) {  // :55-66
+  if (X::has(F_IMAGE) && R.type == RT_TEX_IMAGE) {  // :55-66
     tally.template add<RT_EV_IMAGE_TEX>();
-    const int img = texs[tex].i0;
-    if (img < 0) return mk(0.f, 1.f, 1.f);
-    const DImage RT_CONST& im = cptr(S.images)[img];
-    const int w = im.w, h = im.h;
+    if (R.i0 < 0) return mk(0.f, 1.f, 1.f);
+    const int w = R.w, h = R.h, first_texel = R.i1;
     float uu = (0.0f > u) ? 0.0f : (u > 1.0f ? 1.0f : u);   // clamp, base.clj:307-310 (NaN stays)
     float vc = (0.0f > v) ? 0.0f : (v > 1.0f ? 1.0f : v);
     float vv = 1.0f - vc;
@@ -1212,7 +1217,7 @@ RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, T& tally)
     int j = (fj != fj) ? 0 : (int)fj;
     if (i >= w) i = w - 1;
     if (j >= h) j = h - 1;
-    uint32_t px = cptr(S.texels)[im.first_texel + j * w + i];
+    uint32_t px = cptr(S.texels)[first_texel + j * w + i];
     const float cs = 1.0f / 255.0f;
     return mk((float)(px & 255u) * cs, (float)((px >> 8) & 255u) * cs, (float)((px >> 16) & 255u) * cs);
   }

@@ -185,9 +185,9 @@ struct DMat {
 
 struct DTex {
   int32_t type;  // RT_TEX_*
-  int32_t i0, i1;  // checker: odd, even | noise: perlin id, scale | image: image id
+  int32_t i0, i1;  // checker: odd, even | noise: perlin id, scale | image: image id (-1: none), first texel
   float r, g, b;   // solid colour
-  int32_t pad[2];
+  int32_t w, h;    // image: its size (a copy of the DImage, so a lookup is record -> texel, not record -> image -> texel)
 };
 
 struct DImage {
