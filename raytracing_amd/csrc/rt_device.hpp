@@ -1174,9 +1174,27 @@ RT_DEV bool sin_negative(double x) {
   return ((long long)q & 1LL) != 0;
 }
 
-// texture.clj: value of texture `tex` at (u, v, p).
+// A hit point ON a coordinate plane through the origin (a rect with k = 0): the reference's point o + t d
+// (FP64, ray-at) misses that plane by a rounding error or lands on it, and a checker reads the SIGN of
+// sin(10 coordinate) there (texture.clj:25-30) - the sign of that rounding error, a speckle of both colours.
+// The same three FP64 operations on the incoming ray give a sign of the same kind: +-1e-30, or 0.
+RT_DEV float plane_residual(float o, float d) {
+  const double oc = (double)o, dc = (double)d;
+  const double t = (0.0 - oc) / dc;
+  const double pc = oc + t * dc;
+  return pc > 0.0 ? 1e-30f : (pc < 0.0 ? -1e-30f : 0.0f);
+}
+
+// The residual for the first coordinate of p that is exactly 0 (0 when none is).
+RT_DEV float zero_plane_residual(V3 p, V3 ro, V3 rd) {
+  if (!(p.x == 0.0f || p.y == 0.0f || p.z == 0.0f)) return 0.0f;
+  const bool zx = p.x == 0.0f, zy = !zx && p.y == 0.0f;
+  return plane_residual(zx ? ro.x : (zy ? ro.y : ro.z), zx ? rd.x : (zy ? rd.y : rd.z));
+}
+
+// texture.clj: value of texture `tex` at (u, v, p); resid = zero_plane_residual of the hit.
 template <class X, class T>
-RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, T& tally) {
+RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, float resid, T& tally) {
   const DScene& S = ctx.S;
   const DTex RT_CONST* texs = cptr(S.texs);
   // a texture's whole record in one fetch (its fields are not waited for one after the other)
@@ -1188,6 +1206,11 @@ RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, T& tally)
     return TexRec{(int)a.x, (int)a.y, (int)a.z, __uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y), (int)b.z, (int)b.w};
   };
   TexRec R = fetch(tex);
+  if (R.type == RT_TEX_CHECKER && resid != 0.0f) {
+    // (one coordinate: a point on two such planes at once is an edge)
+    const bool zx = p.x == 0.0f, zy = !zx && p.y == 0.0f, zz = !zx && !zy && p.z == 0.0f;
+    p = mk(zx ? resid : p.x, zy ? resid : p.y, zz ? resid : p.z);
+  }
   for (int depth = 0; R.type == RT_TEX_CHECKER && depth < 16; ++depth) {  // :25-30
     tally.template add<RT_EV_CHECKER>();
     bool nx = sin_negative(10.0 * (double)p.x), ny = sin_negative(10.0 * (double)p.y),
@@ -1226,9 +1249,9 @@ RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, T& tally)
 
 // The colour of a textured material: solid colours are folded into the material record.
 template <class X, class T>
-RT_DEV V3 material_colour(const X& ctx, int flags, int tex, V3 solid, const Rec& rec, T& tally) {
+RT_DEV V3 material_colour(const X& ctx, int flags, int tex, V3 solid, const Rec& rec, float resid, T& tally) {
   if constexpr (X::has(F_TEXTURES)) {
-    if (!(flags & DMAT_SOLID)) return texture_value(ctx, tex, rec.u, rec.v, rec.p, tally);
+    if (!(flags & DMAT_SOLID)) return texture_value(ctx, tex, rec.u, rec.v, rec.p, resid, tally);
   }
   return solid;
 }
@@ -1268,14 +1291,18 @@ RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t
   attenuation = mk(0.f, 0.f, 0.f);
   V3 dir = r.d;
   bool ok = false;
+  float resid = 0.0f;  // see plane_residual: only a textured material on a plane through the origin has one
+  if constexpr (X::has(F_TEXTURES)) {
+    if (!(flags & DMAT_SOLID)) resid = zero_plane_residual(rec.p, r.o, r.d);
+  }
   if (type == RT_MAT_LAMBERTIAN) {  // :16-23
     tally.template add<RT_EV_LAMBERT>();
     dir = rec.n + unit(PRE ? sv : random_in_unit_sphere(g, bounce, tally));  // random-unit-vector, base.clj:196-197
-    attenuation = material_colour(ctx, flags, tex, rgb, rec, tally);
+    attenuation = material_colour(ctx, flags, tex, rgb, rec, resid, tally);
     ok = true;
   } else if (type == RT_MAT_DIFFUSE_LIGHT) {  // :69-78 (the unused scatter direction is not drawn)
     tally.template add<RT_EV_LIGHT>();
-    emitted = material_colour(ctx, flags, tex, rgb, rec, tally);
+    emitted = material_colour(ctx, flags, tex, rgb, rec, resid, tally);
     attenuation = emitted;
   } else if (X::has(F_SPECULAR) && type == RT_MAT_METAL) {  // :33-39
     if constexpr (X::has(F_SPECULAR)) {
@@ -1307,7 +1334,7 @@ RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t
     if constexpr (X::has(F_MEDIA)) {
       tally.template add<RT_EV_ISOTROPIC>();
       dir = PRE ? sv : random_in_unit_sphere(g, bounce, tally);
-      attenuation = material_colour(ctx, flags, tex, rgb, rec, tally);
+      attenuation = material_colour(ctx, flags, tex, rgb, rec, resid, tally);
       ok = true;
     }
   }

@@ -73,3 +73,28 @@ def test_image_textured_world(gpu_ctx, oracle):
         acc = acc + rad[:, :, k, :]
     assert np.array_equal(acc.view(np.uint32), rgb.view(np.uint32))
     sc.close()
+
+
+@pytest.mark.parametrize("make,k", [(xz_rect, 0.3), (xy_rect, -0.7), (xz_rect, 0.0)])
+def test_checker_on_a_plane_through_the_origin_speckles_as_the_reference(gpu_ctx, oracle, make, k):
+    """`^long k` puts a rect with |k| < 1 into the coordinate plane through the origin (rectangles.clj:11). There
+    the reference's hit point o + t d (FP64, ray-at) is off the plane by a rounding error or on it, and the checker
+    (texture.clj:25-30) reads the sign of sin(10 coordinate): the sign of that rounding error, so both colours
+    speckle the rect instead of alternating in cells. The device reproduces the error's sign with the same three
+    FP64 operations: its frame has the oracle's mix of the two colours, not the all-even rect an exact 0 gives."""
+    even, odd = [0.9, 0.9, 0.9], [0.1, 0.8, 0.1]
+    flat = flatten.flatten_world([make(-20, 20, -20, 20, k, lambertian(checker_texture(odd, even)))])
+    cfg = {"lookfrom": [3.0, 6.0, -9.0], "lookat": [0.0, 0.0, 0.0], "vfov": 50.0, "aperture": 0.0, "background": [1.0, 1.0, 1.0]}
+    cam = build_camera(cfg, 1.0)
+    sc = gpu_ctx.scene(flat)
+    p = abi.make_params(64, 64, 64, 2, cfg["background"], seed=5)   # depth 2: one bounce, then the white sky
+    dev = sc.render(cam, p)[0].reshape(-1, 3).astype(np.float64) / 64
+    orc = oracle.render(flat, cam, p, nthreads=8, want_argb=False)[0].reshape(-1, 3) / 64
+    hit = orc[:, 1] < 0.999      # pixels that see the rect
+    assert hit.sum() > 1000
+    d_mean, o_mean = dev[hit].mean(axis=0), orc[hit].mean(axis=0)
+    print(f"[parity] checker rect at k = {int(k)}: device mean {d_mean}, oracle mean {o_mean}")
+    # the oracle does speckle (an all-even rect would be 0.9 grey) and the device has the same mix
+    assert abs(o_mean[0] - 0.9) > 0.003
+    assert np.abs(d_mean - o_mean).max() < 4e-3
+    sc.close()
