@@ -202,15 +202,13 @@ int validate_desc(const rt_scene_desc* d) {
 }
 
 // ------------------------------------------------------------------------------ flattening
-struct Sink {  // leaves reached under each chain, in scan order, duplicates dropped
-  std::vector<int> chain_order;
-  std::map<int, std::vector<int>> prims;
+struct Sink {  // leaves in scan order with the chain each was reached under, duplicates dropped
+  std::vector<std::pair<int, int>> seq;  // (chain, primitive)
   std::set<std::pair<int, int>> seen;
   std::set<std::pair<int, int>> walked;  // (node, chain) already expanded into this sink
   void add(int chain, int prim) {
     if (!seen.insert({chain, prim}).second) return;
-    if (!prims.count(chain)) chain_order.push_back(chain);
-    prims[chain].push_back(prim);
+    seq.push_back({chain, prim});
   }
 };
 
@@ -532,8 +530,41 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
   bool drop_shadowed_spheres = true;  // surface groups; switched off while media boundaries are emitted
   int n_shadowed_total = 0;
   auto emit_groups = [&](const Sink& sink) {
-    for (int chain : sink.chain_order) {
-      std::vector<int> list = sink.prims.at(chain);
+    // Groups are tested one after the other and a rect accepts t = closest-so-far (rectangles.clj), so on an exact
+    // tie the group tested LATER wins - as the later primitive does in the reference's scan. The groups therefore
+    // follow the scan: a group is a run of consecutive leaves under one chain. A later run of a chain joins an
+    // earlier one (fewer groups) only where that cannot reorder a tie: no group in between holds a rect of an
+    // orientation the run holds too. (Two XZ rects at one height under different rotate-y wrappers tie exactly,
+    // whatever the angles: the turn leaves y alone.) Spheres need `<` to displace a hit and never tie by accident.
+    struct Run { int chain; std::vector<int> list; unsigned rect_types; };
+    auto type_bit = [&](int pi) -> unsigned { int t = d->prim_type[pi]; return t >= RT_PRIM_XY_RECT ? 1u << (t - RT_PRIM_XY_RECT) : 0u; };
+    std::vector<Run> runs;
+    for (const auto& cp : sink.seq) {
+      if (runs.empty() || runs.back().chain != cp.first) runs.push_back(Run{cp.first, {}, 0u});
+      runs.back().list.push_back(cp.second);
+      runs.back().rect_types |= type_bit(cp.second);
+    }
+    // merge pass: a run joins the nearest earlier run of its chain when nothing between them shares a rect orientation with it
+    for (size_t i = 0; i < runs.size(); ++i) {
+      if (runs[i].list.empty()) continue;
+      unsigned between = 0;
+      for (size_t j = i; j-- > 0;) {
+        if (runs[j].list.empty()) continue;
+        if (runs[j].chain == runs[i].chain) {
+          if (!(between & runs[i].rect_types)) {
+            runs[j].list.insert(runs[j].list.end(), runs[i].list.begin(), runs[i].list.end());
+            runs[j].rect_types |= runs[i].rect_types;
+            runs[i].list.clear();
+          }
+          break;
+        }
+        between |= runs[j].rect_types;
+      }
+    }
+    for (const Run& run : runs) {
+      if (run.list.empty()) continue;
+      const int chain = run.chain;
+      std::vector<int> list = run.list;
       // by type, stably: XY, XZ, YZ rects, then spheres (scan order kept within a type)
       auto type_rank = [&](int pi) { int t = d->prim_type[pi]; return t >= RT_PRIM_XY_RECT ? t - RT_PRIM_XY_RECT : 3; };
       std::stable_sort(list.begin(), list.end(), [&](int x, int y) { return type_rank(x) < type_rank(y); });

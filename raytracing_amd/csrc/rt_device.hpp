@@ -1192,9 +1192,15 @@ RT_DEV float zero_plane_residual(V3 p, V3 ro, V3 rd) {
   return plane_residual(zx ? ro.x : (zy ? ro.y : ro.z), zx ? rd.x : (zy ? rd.y : rd.z));
 }
 
-// texture.clj: value of texture `tex` at (u, v, p); resid = zero_plane_residual of the hit.
+// Where the residual is worked out: at the head of `scatter` (one live value through the material code) or here,
+// inside the checker's branch (the incoming ray stays live instead). Which is cheaper is the register allocator's
+// call and differs by kernel: the noise-only kernels measured 1-2 % faster with the second, the others with the first.
+template <class X>
+constexpr bool residual_in_checker() { return X::has(F_NOISE) && !X::has(F_BVH); }
+
+// texture.clj: value of texture `tex` at (u, v, p); resid = zero_plane_residual of the hit (ro, rd: its ray).
 template <class X, class T>
-RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, float resid, T& tally) {
+RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, float resid, V3 ro, V3 rd, T& tally) {
   const DScene& S = ctx.S;
   const DTex RT_CONST* texs = cptr(S.texs);
   // a texture's whole record in one fetch (its fields are not waited for one after the other)
@@ -1206,10 +1212,13 @@ RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, float res
     return TexRec{(int)a.x, (int)a.y, (int)a.z, __uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y), (int)b.z, (int)b.w};
   };
   TexRec R = fetch(tex);
-  if (R.type == RT_TEX_CHECKER && resid != 0.0f) {
-    // (one coordinate: a point on two such planes at once is an edge)
-    const bool zx = p.x == 0.0f, zy = !zx && p.y == 0.0f, zz = !zx && !zy && p.z == 0.0f;
-    p = mk(zx ? resid : p.x, zy ? resid : p.y, zz ? resid : p.z);
+  if (R.type == RT_TEX_CHECKER) {
+    if constexpr (residual_in_checker<X>()) resid = zero_plane_residual(p, ro, rd);
+    if (resid != 0.0f) {
+      // (one coordinate: a point on two such planes at once is an edge)
+      const bool zx = p.x == 0.0f, zy = !zx && p.y == 0.0f, zz = !zx && !zy && p.z == 0.0f;
+      p = mk(zx ? resid : p.x, zy ? resid : p.y, zz ? resid : p.z);
+    }
   }
   for (int depth = 0; R.type == RT_TEX_CHECKER && depth < 16; ++depth) {  // :25-30
     tally.template add<RT_EV_CHECKER>();
@@ -1249,9 +1258,9 @@ RT_DEV V3 texture_value(const X& ctx, int tex, float u, float v, V3 p, float res
 
 // The colour of a textured material: solid colours are folded into the material record.
 template <class X, class T>
-RT_DEV V3 material_colour(const X& ctx, int flags, int tex, V3 solid, const Rec& rec, float resid, T& tally) {
+RT_DEV V3 material_colour(const X& ctx, int flags, int tex, V3 solid, const Rec& rec, float resid, const Ray& r, T& tally) {
   if constexpr (X::has(F_TEXTURES)) {
-    if (!(flags & DMAT_SOLID)) return texture_value(ctx, tex, rec.u, rec.v, rec.p, resid, tally);
+    if (!(flags & DMAT_SOLID)) return texture_value(ctx, tex, rec.u, rec.v, rec.p, resid, r.o, r.d, tally);
   }
   return solid;
 }
@@ -1292,17 +1301,17 @@ RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t
   V3 dir = r.d;
   bool ok = false;
   float resid = 0.0f;  // see plane_residual: only a textured material on a plane through the origin has one
-  if constexpr (X::has(F_TEXTURES)) {
+  if constexpr (X::has(F_TEXTURES) && !residual_in_checker<X>()) {
     if (!(flags & DMAT_SOLID)) resid = zero_plane_residual(rec.p, r.o, r.d);
   }
   if (type == RT_MAT_LAMBERTIAN) {  // :16-23
     tally.template add<RT_EV_LAMBERT>();
     dir = rec.n + unit(PRE ? sv : random_in_unit_sphere(g, bounce, tally));  // random-unit-vector, base.clj:196-197
-    attenuation = material_colour(ctx, flags, tex, rgb, rec, resid, tally);
+    attenuation = material_colour(ctx, flags, tex, rgb, rec, resid, r, tally);
     ok = true;
   } else if (type == RT_MAT_DIFFUSE_LIGHT) {  // :69-78 (the unused scatter direction is not drawn)
     tally.template add<RT_EV_LIGHT>();
-    emitted = material_colour(ctx, flags, tex, rgb, rec, resid, tally);
+    emitted = material_colour(ctx, flags, tex, rgb, rec, resid, r, tally);
     attenuation = emitted;
   } else if (X::has(F_SPECULAR) && type == RT_MAT_METAL) {  // :33-39
     if constexpr (X::has(F_SPECULAR)) {
@@ -1334,7 +1343,7 @@ RT_DEV bool scatter(const X& ctx, const Rec& rec, Ray& r, const Rng& g, uint32_t
     if constexpr (X::has(F_MEDIA)) {
       tally.template add<RT_EV_ISOTROPIC>();
       dir = PRE ? sv : random_in_unit_sphere(g, bounce, tally);
-      attenuation = material_colour(ctx, flags, tex, rgb, rec, resid, tally);
+      attenuation = material_colour(ctx, flags, tex, rgb, rec, resid, r, tally);
       ok = true;
     }
   }
