@@ -78,7 +78,10 @@ def _shape(rng, mat, extent, allowed=None):
         kk = float(c[2]) if abs(c[2]) >= 1.0 else float(c[2]) + (1.0 if c[2] >= 0 else -1.0)
         return (xy_rect, xz_rect, yz_rect)[k - 2](a0, a1, b0, b1, kk, mat)
     if k == 5:
-        return box(list(c), list(c + rng.uniform(0.5, 4, 3)), mat)
+        # (no face in a coordinate plane through the origin either: box.clj hands its six k to `^long`)
+        lo, hi = c, c + rng.uniform(0.5, 4, 3)
+        off = lambda v: np.where(np.abs(v) >= 1.0, v, v + np.where(v >= 0, 1.0, -1.0))
+        return box(list(off(lo)), list(np.maximum(off(hi), off(lo) + 0.5)), mat)
     return hittable_list([_shape(rng, mat, extent) for _ in range(int(rng.integers(2, 4)))])
 
 
