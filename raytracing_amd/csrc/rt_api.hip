@@ -237,10 +237,13 @@ struct Flattener {
     return (int)chains.size() - 1;
   }
 
-  // A subtree reached a second time under the same chain adds nothing (its leaves are already in the
-  // sink, in the place of their first occurrence), so it is not expanded again: a description that
-  // shares subtrees (the reference's bvhnode does, base.clj:143-160) costs what it holds, not what it
-  // unfolds to. Depth is bounded because the walk recurses on the host stack.
+  // The walk runs through the description BACKWARDS (last child first) and the sinks are turned round at the end:
+  // a leaf then stands where the scan meets it for the LAST time. That is the occurrence that decides an exact
+  // tie - a rect accepts t = closest-so-far (rectangles.clj), so of two coinciding rects the one the scan tests
+  // later wins, and a wall listed twice wins from its second place. A subtree reached again under the same
+  // chain (going backwards: reached earlier in the scan) adds nothing, so it is not expanded again: a
+  // description that shares subtrees (the reference's bvhnode does, base.clj:143-160) costs what it holds, not
+  // what it unfolds to. Depth is bounded because the walk recurses on the host stack.
   void walk(int node, int chain, Sink& sink, bool in_boundary, int depth = 0) {
     if (err) return;
     if (on_stack[node]) { err = fail(RT_ERR_ARG, "node %d: the hittable tree has a cycle", node); return; }
@@ -254,11 +257,11 @@ struct Flattener {
         sink.add(chain, ni[0]);
         break;
       case RT_NODE_LIST:
-        for (int c = 0; c < ni[1] && !err; ++c) walk(d->node_children[ni[0] + c], chain, sink, in_boundary, depth + 1);
+        for (int c = ni[1]; c-- > 0 && !err;) walk(d->node_children[ni[0] + c], chain, sink, in_boundary, depth + 1);
         break;
       case RT_NODE_BVH:
-        walk(ni[0], chain, sink, in_boundary, depth + 1);
         walk(ni[1], chain, sink, in_boundary, depth + 1);
+        walk(ni[0], chain, sink, in_boundary, depth + 1);
         break;
       case RT_NODE_TRANSLATE:
       case RT_NODE_ROTATE_Y: {
@@ -477,6 +480,8 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
   F.on_stack.assign((size_t)d->n_nodes, 0);
   F.walk(d->root, 0, F.surface, false);
   if (F.err) return F.err;
+  std::reverse(F.surface.seq.begin(), F.surface.seq.end());
+  for (HostMedium& M : F.media) std::reverse(M.boundary.seq.begin(), M.boundary.seq.end());
 
   // device primitive records, one contiguous run per group
   std::vector<DPrim> prims;

@@ -2,6 +2,8 @@
 aim at where the two formulations could part: rays that start inside a box or on a face, rays
 along the axes, rays through edges and corners (exact ties between faces), boxes sharing a group
 with loose rects, and six rects that only look like a box (two materials: not merged)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -252,7 +254,11 @@ def _lattice_world(rng):
     return [world[i] for i in order]
 
 
-@pytest.mark.parametrize("seed", range(12))
+# (RT_LATTICE_SWEEP=<first seed>:<count> runs other worlds than the suite's twelve)
+_SEEDS = range(12) if not os.environ.get("RT_LATTICE_SWEEP") else range(*(lambda a, b: (a, a + b))(*map(int, os.environ["RT_LATTICE_SWEEP"].split(":"))))
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
 def test_random_lattice_worlds_against_the_oracle(gpu_ctx, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     flat = flatten.flatten_world(_lattice_world(rng))

@@ -62,3 +62,35 @@ def test_a_chain_met_twice_is_not_pulled_ahead_of_what_lies_between(gpu_ctx, ora
         assert np.array_equal(dev["hit"] != 0, hit) and hit.sum() > n // 2
         assert np.array_equal(dev["mat_id"][hit], orc[hit, 10].astype(np.int32))
         sc.close()
+
+
+@pytest.mark.parametrize("padding", [0, 30])
+def test_a_wall_listed_twice_wins_from_its_second_place(gpu_ctx, oracle, padding):
+    """The scan tests an object as often as the world lists it, and a rect accepts t = closest-so-far: A, B, A with
+    A and B in one plane gives the overlap to A (its second test comes after B's), A, B gives it to B. With
+    `padding` rects elsewhere the group is big enough for a tree, whose leaf test decides ties on scan ranks."""
+    from raytracing_amd.hittables import yz_rect
+    A = yz_rect(-4, 4, 4, 8, 8.0, lambertian([0.9, 0.1, 0.1]))
+    B = yz_rect(-8, 0, 4, 16, 8.0, lambertian([0.1, 0.9, 0.1]))
+    far = [xy_rect(40 + 3 * i, 42 + 3 * i, 40, 42, 50.0 + i, lambertian([0.5, 0.5, 0.5])) for i in range(padding)]
+    rng = np.random.default_rng(9)
+    n = 3000
+    o = np.stack([rng.uniform(10, 14, n) * rng.choice([-1, 1], n) + 8, rng.uniform(-9, 5, n), rng.uniform(3, 17, n)], axis=1).astype(np.float32)
+    target = np.stack([np.full(n, 8.0), rng.uniform(-9, 5, n), rng.uniform(3, 17, n)], axis=1)
+    d = (target - o).astype(np.float32)
+    winners = {}
+    for name, world in (("ABA", [A, B, A]), ("AB", [A, B]), ("BAB", [B, A, B]), ("far A far B far A", far[:10] + [A] + far[10:20] + [B] + far[20:] + [A])):
+        flat = flatten.flatten_world(world + (far if len(world) <= 3 else []))
+        sc = gpu_ctx.scene(flat)
+        assert (sc.info()["n_bvh_nodes"] > 0) == (padding > 0)
+        dev = sc.hit_batch(o, d)
+        orc = oracle.hit_batch(flat, o, d)
+        hit = orc[:, 11] != 0
+        assert np.array_equal(dev["hit"] != 0, hit) and hit.sum() > n // 3
+        assert np.array_equal(dev["mat_id"][hit], orc[hit, 10].astype(np.int32)), name
+        both = hit & (target[:, 1] > -4) & (target[:, 1] < 0) & (target[:, 2] > 4) & (target[:, 2] < 8)   # the overlap
+        winners[name] = set(int(m) for m in np.unique(dev["mat_id"][both]))
+        assert len(winners[name]) == 1 and both.sum() > 50
+        sc.close()
+    # (materials are numbered as the world first lists them: in "ABA" and "AB" A's is 0, in "BAB" B's is)
+    assert winners["ABA"] == {0} and winners["AB"] == {1} and winners["BAB"] == {0}
