@@ -203,6 +203,24 @@ constexpr bool wave_draw(uint32_t feat) {
   return RT_WAVE_DRAW_SPH != 0;
 }
 
+// Where shading costs far more than finding the hit (a noise texture's seven octaves against two or three sphere
+// tests), a path that misses leaves its lane idle through the whole shading phase. The kernels of such worlds hold
+// their hits back: lanes whose path ended take their next sample and look again, and the wave shades when
+// RT_SHADE_MIN lanes hold a hit (or nothing else can be done, or RT_SHADE_WAIT rounds went by). Samples are keyed,
+// and a lane still takes its item's samples in order: the frame is the same, bit for bit.
+#ifndef RT_SHADE_MIN
+#define RT_SHADE_MIN 52
+#endif
+#ifndef RT_SHADE_WAIT
+#define RT_SHADE_WAIT 3
+#endif
+#ifndef RT_DEFER_NOISE
+#define RT_DEFER_NOISE 1
+#endif
+constexpr bool defer_shading(uint32_t feat) {
+  return RT_DEFER_NOISE != 0 && (feat & F_NOISE) && !(feat & (F_BVH | F_MEDIA | F_CHAINS | F_SMALL)) && wave_draw(feat);
+}
+
 // All arguments of k_render in one struct, so that its layout IS the kernarg segment's. Fields the
 // loop needs rarely (the camera's 21 doubles, the queue geometry) are not kept in SGPRs across the
 // traversal loops, where they would be spilled into VGPR lanes and read back with VALU
@@ -262,6 +280,11 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
   uint32_t bounce = 0;
   Rng g{0u, 0u, R.seed_lo, R.seed_hi};
   unsigned long long n_rays = 0, n_samples = 0;  // of the whole wave (wave-uniform, scalar registers)
+  // defer_shading: the hit a lane holds back (its record), and how many rounds the wave has held hits back
+  Rec held;
+  held.mtype = -1;
+  bool pending = false;
+  int waited = 0;
   // HW_ID.wave_id (s_getreg id 4, offset 0, 4 bits): the wave's slot in its SIMD
   uint32_t prio_tick = __builtin_amdgcn_s_getreg(6148);
 
@@ -387,7 +410,39 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
 #ifdef RT_STAMPS
     ts3 = ts2; tsi = ts2;
 #endif
-    if constexpr (wave_draw(FEAT)) {
+    if constexpr (defer_shading(FEAT)) {
+      // core.clj:23 for the lanes whose path has no hit in hand; a miss ends the path at once (core.clj:30)
+      const bool look = active && !pending;
+      n_rays += (unsigned long long)__popcll(__ballot(look));
+      if (look) {
+        pending = closest_hit(X, ray, 0.001f, __builtin_inff(), g, bounce, nullptr, false, false, held, tally);
+        if (!pending) {
+          V3 L;
+          path_finish<true>(X, R, false, held, mk(0.f, 0.f, 0.f), ray, beta, bounce, g, L, tally);
+          acc = acc + L;
+          tally.template add<RT_EV_ACCUMULATE>();
+          active = false;
+        }
+      }
+      RT_STAMP(ts3);
+      // shade now? Enough hits in hand, or no lane left that could still find one, or waited long enough
+      const int n_pending = __popcll(__ballot(pending));
+      const bool can_look = __ballot(!pending && !done) != 0ull;
+      ++waited;
+      if (n_pending >= RT_SHADE_MIN || !can_look || waited >= RT_SHADE_WAIT) {  // wave-uniform
+        waited = 0;
+        const V3 sv = wave_random_in_unit_sphere(pending && needs_sphere_draw(held.mtype), g, bounce, X.lds_xch, tally);
+        if (pending) {
+          V3 L;
+          if (path_finish<true>(X, R, true, held, sv, ray, beta, bounce, g, L, tally)) {
+            acc = acc + L;  // core.clj:120
+            tally.template add<RT_EV_ACCUMULATE>();
+            active = false;
+          }
+          pending = false;
+        }
+      }
+    } else if constexpr (wave_draw(FEAT)) {
       // core.clj:23: the closest hit, for the lanes that carry a path
       Rec rec;
       rec.mtype = -1;
