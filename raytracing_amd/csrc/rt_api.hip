@@ -1039,6 +1039,9 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
   sc->tree_height = max_height;
   S.bvh_stack = n_bvh_nodes ? max_height + 1 : 0;
   S.n_bvh_nodes = n_bvh_nodes;
+  // the second half of every packed node also lives in LDS when the trees are small enough for that not to
+  // cost the kernel a resident workgroup (16 bytes per node and workgroup)
+  S.lds_nodes = n_bvh_nodes <= RT_LDS_NODE_MAX ? n_bvh_nodes : 0;
   {
     std::vector<int32_t> bvh_next(groups.size(), -1);
     int next = -1;
@@ -1077,10 +1080,15 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
   S.n_perlin = d->n_perlin;
 
   // the largest instantiation's need bounds every kernel this scene may run on (hit and scatter hooks included)
-  size_t lds = shade_lds_bytes(S, RT_BLOCK);
-  size_t lds_any = lds;
-  for (int v = 0; v < RT_N_VARIANTS; ++v)
-    if (variant_covers(S, v)) lds_any = std::max(lds_any, variant_lds_bytes(S, RT_BLOCK, v));
+  size_t lds = 0, lds_any = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    lds = shade_lds_bytes(S, RT_BLOCK);
+    lds_any = lds;
+    for (int v = 0; v < RT_N_VARIANTS; ++v)
+      if (variant_covers(S, v)) lds_any = std::max(lds_any, variant_lds_bytes(S, RT_BLOCK, v));
+    if (lds_any <= ctx->lds_max || S.lds_nodes == 0) break;
+    S.lds_nodes = 0;  // a deep tree's stacks leave no room for the node halves: they are read from memory
+  }
   if (lds_any > ctx->lds_max)
     return fail(RT_ERR_UNSUPPORTED, "scene needs %zu bytes of LDS per workgroup (BVH height %d); this device allows %zu",
                 lds_any, max_height, ctx->lds_max);

@@ -249,6 +249,8 @@ struct Ctx {
   uint32_t RT_LDS* lds_xch;         // this wave's 1 KiB exchange area (wave_random_in_unit_sphere)
   int* lds_stack;                   // BVH stack base of this lane (stride = blockDim.x)
   int stack_stride;
+  typedef uint32_t node_q __attribute__((ext_vector_type(4)));
+  const node_q RT_LDS* lds_node_half;  // second halves of the packed tree nodes in LDS (null: read them from memory)
 #ifdef RT_STAMPS
   unsigned long long* st_leaf;      // diagnostic build: wave cycles spent in BVH leaf tests,
   unsigned long long* st_walk;      //   in the walk between them, and the number of leaf rounds
@@ -495,7 +497,7 @@ RT_DEV bool slab16(_Float16 cx, _Float16 cy, _Float16 cz, _Float16 hx, _Float16 
 // has nothing left. Leaves are visited out of scan order: test_prim_any_order applies the
 // reference's tie rule explicitly.
 #define RT_BVH_DONE 0x7fffffff
-template <class X, class T>
+template <bool LDSQ, class X, class T>
 RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best& best, T& tally, double tmin64) {
   const DScene& S = ctx.S;
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -549,7 +551,26 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
 #ifdef RT_STAMPS
     __builtin_amdgcn_sched_barrier(0); st_a = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #endif
-    while ((unsigned)node < (unsigned)RT_BVH_DONE) step(nodes4[node * 2 + 0], nodes4[node * 2 + 1]);  // internal
+    // A step's 32 bytes per lane arrive over two pipes when the trees fit: the first half of the record
+    // through the vector memory pipe, the second half from its copy in LDS. The walk is held by the
+    // rate at which the memory pipe returns 16 bytes per lane (its data path is busy nine cycles in ten
+    // with both halves on it), not by instruction issue.
+    if constexpr (LDSQ) {
+      while ((unsigned)node < (unsigned)RT_BVH_DONE) step(nodes4[node * 2 + 0], ctx.lds_node_half[node]);  // internal
+    } else {
+#ifdef RT_EXTRA_LOAD
+      // diagnostic build (tools/ab_build.sh): one more 16-byte fetch per lane and step, its value unused and off the
+      // walk's dependency chain: what it costs is the share of the vector memory pipe in the walk's time
+      // (needs an even number of nodes: it reads the sibling record)
+      while ((unsigned)node < (unsigned)RT_BVH_DONE) {
+        const u4 extra = reinterpret_cast<const u4*>(S.nodes)[(node * 2 + 1) ^ 2];
+        asm volatile("" :: "v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
+        step(nodes4[node * 2 + 0], nodes4[node * 2 + 1]);
+      }
+#else
+      while ((unsigned)node < (unsigned)RT_BVH_DONE) step(nodes4[node * 2 + 0], nodes4[node * 2 + 1]);  // internal
+#endif
+    }
 #ifdef RT_STAMPS
     __builtin_amdgcn_sched_barrier(0); st_b = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -784,7 +805,10 @@ RT_DEV void group_hit(const X& ctx, int g, const Ray& wr, float tmin, Best& best
   const RayX r = group_ray<X>(S, g, G.flags, G.rc, G.rs, G.bx, G.by, G.bz, wr, tally);
   const int bvh_root = G.bvh_root;
   if (X::has(F_BVH) && bvh_root >= 0) {
-    if constexpr (X::has(F_BVH)) bvh_traverse(ctx, bvh_root, r, tmin, best, tally, tmin64);
+    if constexpr (X::has(F_BVH)) {
+      if (ctx.lds_node_half) bvh_traverse<true>(ctx, bvh_root, r, tmin, best, tally, tmin64);  // scene-uniform
+      else bvh_traverse<false>(ctx, bvh_root, r, tmin, best, tally, tmin64);
+    }
   } else {
     brute_group_hit<X>(S, G, r, tmin, best, tally, tmin64);
   }

@@ -54,6 +54,8 @@ namespace rt {
 //   [.., + n_prims*96 + n_chains*64)   DPrimInfo and DChainRec tables (F_SMALL instantiations only)
 //   [.., + blockDim/64 * 1024)         one exchange area per wave (wave_random_in_unit_sphere)
 //   [.., + blockDim*bvh_stack*4)       per-lane BVH stacks, entry e of lane l at e*blockDim + l
+//   [.., + lds_nodes*16)               the second half of every packed tree node (instantiations that walk trees,
+//                                      when the scene's trees fit: DScene::lds_nodes)
 template <uint32_t FEAT>
 __device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* lds) {
   Ctx<FEAT> X;
@@ -90,6 +92,17 @@ __device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* ld
   const size_t xch_bytes = (size_t)(blockDim.x >> 6) * 1024;
   X.lds_stack = reinterpret_cast<int*>(lds + vec_bytes + perm_bytes + info_bytes + xch_bytes) + threadIdx.x;
   X.stack_stride = blockDim.x;
+  X.lds_node_half = nullptr;
+  if constexpr ((FEAT & F_BVH) != 0) {
+    if (S.lds_nodes > 0) {  // scene-uniform
+      typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+      u4* ln = reinterpret_cast<u4*>(lds + vec_bytes + perm_bytes + info_bytes + xch_bytes + (size_t)blockDim.x * (size_t)S.bvh_stack * 4);
+      const u4* gn = reinterpret_cast<const u4*>(S.nodes);
+      for (int i = threadIdx.x; i < S.lds_nodes; i += blockDim.x) ln[i] = gn[i * 2 + 1];
+      __syncthreads();
+      X.lds_node_half = (const u4 RT_LDS*)ln;
+    }
+  }
 #ifdef RT_STAMPS
   X.st_leaf = X.st_walk = X.st_rounds = nullptr; X.st_grp = nullptr;
 #endif
@@ -703,7 +716,8 @@ size_t variant_lds_bytes(const DScene& S, int block, int variant) {
   size_t vec_bytes = (size_t)S.n_perlin * 4096;
   size_t perm_bytes = ((size_t)S.n_perlin * 768 + 15) & ~(size_t)15;
   size_t info_bytes = variant < 2 ? (size_t)S.n_prims * sizeof(DPrimInfo) + (size_t)S.n_chains * sizeof(DChainRec) : 0;
-  return vec_bytes + perm_bytes + info_bytes + (size_t)(block / 64) * 1024 + (size_t)block * (size_t)S.bvh_stack * 4;
+  const size_t node_bytes = (variant == 3 || variant >= 5) ? (size_t)S.lds_nodes * 16 : 0;
+  return vec_bytes + perm_bytes + info_bytes + (size_t)(block / 64) * 1024 + (size_t)block * (size_t)S.bvh_stack * 4 + node_bytes;
 }
 size_t shade_lds_bytes(const DScene& S, int block) { return variant_lds_bytes(S, block, pick_variant(S)); }
 
@@ -774,6 +788,7 @@ hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, 
     return with_pool_kernel(S, count, [&](auto kernel) {
       RenderArgs A;
       A.S = S; A.cam = cam; A.R = R; A.out = out; A.queue = queue; A.stats = stats;
+      A.S.lds_nodes = 0;  // the pool has its own LDS layout and its own walk
       hipLaunchKernelGGL(kernel, dim3(grid), dim3(RT_BLOCK), lds, stream, A);
       return hipGetLastError();
     });

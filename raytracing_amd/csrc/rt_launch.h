@@ -9,6 +9,11 @@
 
 #define RT_BLOCK 256  // threads per workgroup of the path kernels (4 waves)
 
+// Trees of up to this many nodes keep the second half of each packed node in LDS (see bvh_traverse).
+#ifndef RT_LDS_NODE_MAX
+#define RT_LDS_NODE_MAX 1024
+#endif
+
 namespace rt {
 
 size_t shade_lds_bytes(const DScene& S, int block);
