@@ -531,9 +531,23 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
     for (int a = 0; a < 3; ++a) { c[a] = 0.5 * (lo[a] + hi[a]); e = std::max(e, hi[a] - lo[a]); }
     return e;
   };
-  std::function<void(int, std::vector<int>)> emit_one;
+  // A list entry is a primitive of the description and, for a sphere carried into world space (below), the
+  // chain its record still goes through: primitive | record chain << 32.
+  typedef long long Entry;
+  auto e_prim = [](Entry e) { return (int)(e & 0xffffffffll); };
+  auto e_chain = [](Entry e) { return (int)(e >> 32); };
+  std::function<void(int, std::vector<Entry>)> emit_one;
   bool drop_shadowed_spheres = true;  // surface groups; switched off while media boundaries are emitted
   int n_shadowed_total = 0;
+  // Spheres below a chain are intersected in WORLD space: a chain is a rigid motion, so the sphere carried
+  // through its inverse meets the world ray at the same t. They join the groups (and trees) of the
+  // chain-less primitives instead of forming groups of their own, each of which costs every ray an FP64
+  // ray transform and a tree walk as long as its slowest lane's. Their records are still built in the
+  // chain's space from the untouched primitive (prims_rec) and unwound through the chain: the primitive's
+  // group is a header group that holds the chain's motion and is never tested.
+  std::vector<DPrim> prims_rec;
+  std::vector<std::pair<size_t, int>> world_spheres;  // (device primitive, record chain), headers assigned later
+  bool spheres_to_world = true;
   auto emit_groups = [&](const Sink& sink) {
     // Groups are tested one after the other and a rect accepts t = closest-so-far (rectangles.clj), so on an exact
     // tie the group tested LATER wins - as the later primitive does in the reference's scan. The groups therefore
@@ -541,12 +555,14 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
     // earlier one (fewer groups) only where that cannot reorder a tie: no group in between holds a rect of an
     // orientation the run holds too. (Two XZ rects at one height under different rotate-y wrappers tie exactly,
     // whatever the angles: the turn leaves y alone.) Spheres need `<` to displace a hit and never tie by accident.
-    struct Run { int chain; std::vector<int> list; unsigned rect_types; };
+    struct Run { int chain; std::vector<Entry> list; unsigned rect_types; };
     auto type_bit = [&](int pi) -> unsigned { int t = d->prim_type[pi]; return t >= RT_PRIM_XY_RECT ? 1u << (t - RT_PRIM_XY_RECT) : 0u; };
     std::vector<Run> runs;
     for (const auto& cp : sink.seq) {
-      if (runs.empty() || runs.back().chain != cp.first) runs.push_back(Run{cp.first, {}, 0u});
-      runs.back().list.push_back(cp.second);
+      const bool to_world = spheres_to_world && cp.first != 0 && d->prim_type[cp.second] <= RT_PRIM_MOVING_SPHERE;
+      const int chain = to_world ? 0 : cp.first;
+      if (runs.empty() || runs.back().chain != chain) runs.push_back(Run{chain, {}, 0u});
+      runs.back().list.push_back((Entry)cp.second | ((Entry)(to_world ? cp.first : 0) << 32));
       runs.back().rect_types |= type_bit(cp.second);
     }
     // merge pass: a run joins the nearest earlier run of its chain when nothing between them shares a rect orientation with it
@@ -569,10 +585,10 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
     for (const Run& run : runs) {
       if (run.list.empty()) continue;
       const int chain = run.chain;
-      std::vector<int> list = run.list;
+      std::vector<Entry> list = run.list;
       // by type, stably: XY, XZ, YZ rects, then spheres (scan order kept within a type)
-      auto type_rank = [&](int pi) { int t = d->prim_type[pi]; return t >= RT_PRIM_XY_RECT ? t - RT_PRIM_XY_RECT : 3; };
-      std::stable_sort(list.begin(), list.end(), [&](int x, int y) { return type_rank(x) < type_rank(y); });
+      auto type_rank = [&](Entry e) { int t = d->prim_type[e_prim(e)]; return t >= RT_PRIM_XY_RECT ? t - RT_PRIM_XY_RECT : 3; };
+      std::stable_sort(list.begin(), list.end(), [&](Entry x, Entry y) { return type_rank(x) < type_rank(y); });
       // A BVH over Morton codes is only as good as its primitives are alike in size: one huge
       // primitive (the r = 1000 ground spheres of the random-spheres world) inflates the box of
       // every ancestor it has and stretches the Morton grid until the small primitives share a few
@@ -582,11 +598,11 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
       if ((int)list.size() > RT_BRUTE_MAX) {
         std::vector<double> ext(list.size());
         std::vector<std::array<double, 3>> ctr(list.size());
-        for (size_t i = 0; i < list.size(); ++i) ext[i] = prim_extent(list[i], ctr[i].data());
+        for (size_t i = 0; i < list.size(); ++i) ext[i] = prim_extent(e_prim(list[i]), ctr[i].data());
         std::vector<double> sorted = ext;
         std::nth_element(sorted.begin(), sorted.begin() + (long)sorted.size() / 2, sorted.end());
         const double median = sorted[sorted.size() / 2];
-        std::vector<int> huge, rest;
+        std::vector<Entry> huge, rest;
         for (size_t i = 0; i < list.size(); ++i)
           (ext[i] > 16.0 * median && median > 0.0 ? huge : rest).push_back(list[i]);
         if (!huge.empty() && (int)huge.size() <= RT_BRUTE_MAX && !rest.empty()) {
@@ -598,8 +614,27 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
       emit_one(chain, list);
     }
   };
-  emit_one = [&](int chain, std::vector<int> list) {
+  emit_one = [&](int chain, std::vector<Entry> list) {
     {
+      // what the device tests: a sphere's centre(s) and radius as the description holds them, or carried
+      // into world space through the inverse of its record chain's motion (o' = Ry(o) + b, see DGroup)
+      auto sphere_fields = [&](Entry e, double out[9]) {
+        const int pi = e_prim(e);
+        const double* pd = d->prim_d + (size_t)pi * RT_PRIM_STRIDE;
+        const int n = d->prim_type[pi] == RT_PRIM_SPHERE ? 4 : 9;
+        for (int k = 0; k < n; ++k) out[k] = pd[k];
+        if (e_chain(e) == 0) return;
+        DGroup G0;
+        DGroup64 H0;
+        std::memset(&G0, 0, sizeof G0);
+        chain_motion(e_chain(e), G0, H0);
+        for (int c0 = 0; c0 < (n == 4 ? 3 : 6); c0 += 3) {
+          const long double lx = (long double)pd[c0] - H0.bx, ly = (long double)pd[c0 + 1] - H0.by, lz = (long double)pd[c0 + 2] - H0.bz;
+          out[c0] = (double)((long double)H0.rc * lx + (long double)H0.rs * lz);
+          out[c0 + 1] = (double)ly;
+          out[c0 + 2] = (double)((long double)H0.rc * lz - (long double)H0.rs * lx);
+        }
+      };
       DGroup G;
       DGroup64 H;
       std::memset(&G, 0, sizeof G);
@@ -617,14 +652,16 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
       size_t n_tested = list.size();
       if (drop_shadowed_spheres) {
         std::map<std::array<double, 4>, int> seen;
-        std::vector<int> kept, shadowed;
-        for (int pi : list) {
+        std::vector<Entry> kept, shadowed;
+        for (Entry e : list) {
+          const int pi = e_prim(e);
           bool dup = false;
           if (d->prim_type[pi] == RT_PRIM_SPHERE) {
-            const double* pd = d->prim_d + (size_t)pi * RT_PRIM_STRIDE;
-            dup = !seen.emplace(std::array<double, 4>{pd[0], pd[1], pd[2], pd[3]}, pi).second;
+            double f[9];
+            sphere_fields(e, f);  // (the fields the device tests: the same numbers give the same roots)
+            dup = !seen.emplace(std::array<double, 4>{f[0], f[1], f[2], f[3]}, pi).second;
           }
-          (dup ? shadowed : kept).push_back(pi);
+          (dup ? shadowed : kept).push_back(e);
         }
         n_tested = kept.size();
         n_shadowed_total += (int)shadowed.size();
@@ -632,7 +669,8 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
         list.insert(list.end(), shadowed.begin(), shadowed.end());
       }
       size_t li = 0;
-      for (int pi : list) {
+      for (Entry e : list) {
+        const int pi = e_prim(e);
         const bool tested = li++ < n_tested;
         DPrim P;
         std::memset(&P, 0, sizeof P);
@@ -645,17 +683,23 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
         if (ptype == RT_PRIM_XY_RECT) G.n_xy++;
         if (ptype == RT_PRIM_XZ_RECT) G.n_xz++;
         if (ptype == RT_PRIM_YZ_RECT) G.n_yz++;
+        DPrim L = P;  // the record's copy: the primitive in its chain's space
         if (ptype == RT_PRIM_SPHERE) {
-          for (int k = 0; k < 4; ++k) P.d[k] = pd[k];
+          for (int k = 0; k < 4; ++k) L.d[k] = pd[k];
+          sphere_fields(e, P.d);
         } else if (ptype == RT_PRIM_MOVING_SPHERE) {
-          for (int k = 0; k < 9; ++k) P.d[k] = pd[k];
+          for (int k = 0; k < 9; ++k) L.d[k] = pd[k];
+          sphere_fields(e, P.d);
           any_moving = true;
           tlo = std::min(tlo, std::min(pd[6], pd[7]));
           thi = std::max(thi, std::max(pd[6], pd[7]));
         } else {
           for (int k = 0; k < 5; ++k) P.f[k] = (float)pd[k];
+          L = P;
         }
+        if (e_chain(e) != 0) world_spheres.push_back({prims.size(), e_chain(e)});
         prims.push_back(P);
+        prims_rec.push_back(L);
       }
       G.first_rect = (int)(brute_rects.size() / RT_PAIR_STRIDE);
       G.first_box = (int)(brute_boxes.size() / RT_BOX_STRIDE);
@@ -815,6 +859,26 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
   };
   emit_groups(F.surface);
   int n_surface_groups = (int)groups.size();
+  spheres_to_world = false;  // boundaries of media keep their spheres in the chain's space
+  {  // one header group per chain that lent spheres to the world-space groups, behind the tested ones
+    std::map<int, int> header;
+    for (const auto& ws : world_spheres) {
+      auto it = header.find(ws.second);
+      if (it == header.end()) {
+        DGroup G;
+        DGroup64 H;
+        std::memset(&G, 0, sizeof G);
+        G.chain = ws.second; G.first_prim = (int)prims.size(); G.bvh_root = -1;
+        G.flags = DGROUP_SPHERES_UNDER_CHAIN;
+        chain_motion(ws.second, G, H);
+        it = header.emplace(ws.second, (int)groups.size()).first;
+        groups.push_back(G);
+        groups64.push_back(H);
+      }
+      prims[ws.first].type = (prims[ws.first].type & 15) | (it->second << 4);
+      prims_rec[ws.first].type = prims[ws.first].type;
+    }
+  }
   if (F.chains.size() > (1u << 20)) return fail(RT_ERR_UNSUPPORTED, "too many distinct instance chains");
   std::vector<DMedium> media((size_t)d->n_media);
   for (int m = 0; m < d->n_media; ++m) {
@@ -990,6 +1054,8 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
   if ((rc = upload(sc, prims, &d_prims))) return rc;
   prims.resize(n_real_prims);
   S.prims = d_prims;
+  S.prims_rec = d_prims;
+  if (!world_spheres.empty() && (rc = upload(sc, prims_rec, &S.prims_rec))) return rc;
 
   // BVHs for the large groups, built on the device: surface-area sweep up to RT_SWEEP_MAX primitives,
   // Morton order beyond (or whichever builder the caller names)

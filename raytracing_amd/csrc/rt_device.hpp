@@ -895,7 +895,7 @@ RT_DEV void prim_record(const DScene& S, int prim, const DPrimInfo& I, const Ray
     if constexpr (X::has(F_SPHERES)) {
       // base.clj:243-246 in FP64 from the FP64 root the winning test kept
       tally.template add<RT_EV_SPHERE_RECORD>();
-      const DPrim RT_CONST& P = cptr(S.prims)[prim];
+      const DPrim RT_CONST& P = cptr(S.prims_rec)[prim];
       D3 c = sphere_center(P, type, r.tm);
       double inv_r = 1.0 / sphere_radius(P, type);
       D3 o64 = rayx_o64<X::has(F_CHAINS)>(r), d64 = rayx_d64<X::has(F_CHAINS)>(r);

@@ -197,7 +197,9 @@ struct DImage {
 };
 
 struct DScene {
-  const DPrim* prims;
+  const DPrim* prims;            // what the intersection tests read
+  const DPrim* prims_rec;        // what a sphere's record reads: the same table, except that a sphere tested in
+                                 // world space (lent by a chain to a chain-less group) stands here in its chain's space
   const float* brute_rects;      // the rects of every brute-force group as PAIRS of one orientation, so one
                                  // packed-FP32 instruction serves two rects: k k' a0 a0' a1 a1' b0 b0' b1 b1'
                                  // then the two device primitive indices (int bits). Per group: XY pairs, XZ
