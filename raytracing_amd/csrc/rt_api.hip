@@ -548,6 +548,7 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
   std::vector<DPrim> prims_rec;
   std::vector<std::pair<size_t, int>> world_spheres;  // (device primitive, record chain), headers assigned later
   bool spheres_to_world = true;
+  const bool lid_boxes_as_leaves = RT_LIDBOX_LEAVES != 0;
   auto emit_groups = [&](const Sink& sink) {
     // Groups are tested one after the other and a rect accepts t = closest-so-far (rectangles.clj), so on an exact
     // tie the group tested LATER wins - as the later primitive does in the reference's scan. The groups therefore
@@ -668,10 +669,110 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
         list = kept;
         list.insert(list.end(), shadowed.begin(), shadowed.end());
       }
+      // Groups that get a tree: six rects that are a box with its lid sunk below the rim (RT_PRIM_LIDBOX, rt_scene.h)
+      // become ONE leaf. The rects are found by exact comparison of their fields, all of one material; they move
+      // behind everything the group tests (their records stay, the leaf names the one that was hit), in the order
+      // they had, so ties among them fall as before. A box is left alone when one of its rects lies in the plane of
+      // a rect that stays in the tree and overlaps it: the later of the two in the scan must win that tie, and behind
+      // the others the box's rect would always be the later one.
+      struct LidBox { float b[6]; float lid; int pos[6]; int mat; };  // pos: places in `list` of the faces z0 z1 y0 x0 x1 and of the lid
+      std::vector<LidBox> lidboxes;
+      std::vector<char> absorbed(list.size(), 0);
+      if ((int)n_tested > RT_BRUTE_MAX && lid_boxes_as_leaves) {
+        auto RF = [&](int pos, int k) { return (float)d->prim_d[(size_t)e_prim(list[(size_t)pos]) * RT_PRIM_STRIDE + k]; };
+        auto TY = [&](int pos) { return d->prim_type[e_prim(list[(size_t)pos])]; };
+        auto MT = [&](int pos) { return d->prim_mat[e_prim(list[(size_t)pos])]; };
+        typedef std::array<float, 6> Key;  // type, a0 a1 b0 b1, material
+        std::map<Key, std::vector<int>> by_shape;
+        for (int pos = 0; pos < (int)n_tested; ++pos)
+          if (TY(pos) >= RT_PRIM_XY_RECT) by_shape[Key{(float)TY(pos), RF(pos, 0), RF(pos, 1), RF(pos, 2), RF(pos, 3), (float)MT(pos)}].push_back(pos);
+        auto find_k = [&](int type, float a0, float a1, float b0, float b1, int mat, float k_lo, float k_hi, int avoid) {
+          // a free rect of that shape whose plane lies in [k_lo, k_hi]
+          auto it = by_shape.find(Key{(float)type, a0, a1, b0, b1, (float)mat});
+          if (it == by_shape.end()) return -1;
+          for (int pos : it->second)
+            if (!absorbed[(size_t)pos] && pos != avoid && RF(pos, 4) >= k_lo && RF(pos, 4) <= k_hi) return pos;
+          return -1;
+        };
+        for (int p = 0; p < (int)n_tested; ++p) {
+          if (TY(p) != RT_PRIM_XY_RECT || absorbed[(size_t)p]) continue;
+          const float x0 = RF(p, 0), x1 = RF(p, 1), y0 = RF(p, 2), y1 = RF(p, 3), za = RF(p, 4);
+          const int mat = MT(p);
+          if (!(x0 < x1 && y0 < y1)) continue;
+          auto it = by_shape.find(Key{(float)RT_PRIM_XY_RECT, x0, x1, y0, y1, (float)mat});
+          for (int q : it->second) {
+            if (q == p || absorbed[(size_t)q] || RF(q, 4) == za) continue;
+            const float z0 = std::min(za, RF(q, 4)), z1 = std::max(za, RF(q, 4));
+            const int fz0 = RF(p, 4) == z0 ? p : q, fz1 = RF(p, 4) == z0 ? q : p;
+            const int fx0 = find_k(RT_PRIM_YZ_RECT, y0, y1, z0, z1, mat, x0, x0, -1);
+            const int fx1 = find_k(RT_PRIM_YZ_RECT, y0, y1, z0, z1, mat, x1, x1, fx0);
+            const int fy0 = find_k(RT_PRIM_XZ_RECT, x0, x1, z0, z1, mat, y0, y0, -1);
+            const int lid = find_k(RT_PRIM_XZ_RECT, x0, x1, z0, z1, mat, std::nextafter(y0, y1), y1, fy0);
+            if (fx0 < 0 || fx1 < 0 || fy0 < 0 || lid < 0) continue;
+            LidBox B{{x0, x1, y0, y1, z0, z1}, RF(lid, 4), {fz0, fz1, fy0, fx0, fx1, lid}, mat};
+            for (int f : B.pos) absorbed[(size_t)f] = 1;
+            lidboxes.push_back(B);
+            break;
+          }
+        }
+        // give up the boxes that share a plane with a rect that stays in the tree
+        for (bool changed = true; changed;) {
+          changed = false;
+          for (size_t bi = 0; bi < lidboxes.size() && !changed; ++bi)
+            for (int f : lidboxes[bi].pos) {
+              auto planes_meet = [&](int a, int b) {
+                return TY(a) == TY(b) && RF(a, 4) == RF(b, 4) && RF(a, 0) < RF(b, 1) && RF(b, 0) < RF(a, 1) && RF(a, 2) < RF(b, 3) && RF(b, 2) < RF(a, 3);
+              };
+              bool meets = false;
+              for (int pos = 0; pos < (int)n_tested && !meets; ++pos)
+                meets = !absorbed[(size_t)pos] && TY(pos) >= RT_PRIM_XY_RECT && planes_meet(f, pos);
+              if (meets) {
+                for (int g : lidboxes[bi].pos) absorbed[(size_t)g] = 0;
+                lidboxes.erase(lidboxes.begin() + (long)bi);
+                changed = true;
+                break;
+              }
+            }
+        }
+      }
+      if (!lidboxes.empty() && (int)(n_tested - 5 * lidboxes.size()) <= RT_BRUTE_MAX) {
+        // too few leaves left for a tree: the brute-force loops know nothing of box leaves
+        lidboxes.clear();
+        std::fill(absorbed.begin(), absorbed.end(), 0);
+      }
+      // the order on the device: what the group tests (its rects by type, its spheres, its box leaves), then
+      // what only keeps a record (shadowed spheres, the rects of the box leaves)
+      std::vector<int> order;        // a place in `list`, or -1 - b for box leaf b
+      std::vector<int> new_place(list.size(), -1);
+      for (int pos = 0; pos < (int)n_tested; ++pos)
+        if (!absorbed[(size_t)pos]) { new_place[(size_t)pos] = (int)order.size(); order.push_back(pos); }
+      for (int b = 0; b < (int)lidboxes.size(); ++b) order.push_back(-1 - b);
+      const size_t n_tested_dev = order.size();
+      for (int pos = (int)n_tested; pos < (int)list.size(); ++pos) { new_place[(size_t)pos] = (int)order.size(); order.push_back(pos); }
+      for (int pos = 0; pos < (int)n_tested; ++pos)
+        if (absorbed[(size_t)pos]) { new_place[(size_t)pos] = (int)order.size(); order.push_back(pos); }
       size_t li = 0;
-      for (Entry e : list) {
+      for (int place : order) {
+        const bool tested = li++ < n_tested_dev;
+        if (place < 0) {  // a box leaf
+          const LidBox& B = lidboxes[(size_t)(-1 - place)];
+          DPrim P;
+          std::memset(&P, 0, sizeof P);
+          P.type = RT_PRIM_LIDBOX | ((int)groups.size() << 4);
+          P.mat = B.mat;
+          for (int k = 0; k < 6; ++k) P.f[k] = B.b[k];
+          P.f[6] = B.lid;
+          for (int k = 0; k < 6; ++k) {
+            const int idx = G.first_prim + new_place[(size_t)B.pos[k]];
+            std::memcpy(&P.f[7 + k], &idx, 4);
+          }
+          G.n_lidbox++;
+          prims.push_back(P);
+          prims_rec.push_back(P);
+          continue;
+        }
+        const Entry e = list[(size_t)place];
         const int pi = e_prim(e);
-        const bool tested = li++ < n_tested;
         DPrim P;
         std::memset(&P, 0, sizeof P);
         const int ptype = d->prim_type[pi];
@@ -680,9 +781,9 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
         const double* pd = d->prim_d + (size_t)pi * RT_PRIM_STRIDE;
         if (ptype <= RT_PRIM_MOVING_SPHERE) { features |= F_SPHERES; G.n_sph += tested ? 1 : 0; }
         if (ptype <= RT_PRIM_MOVING_SPHERE && chain != 0) G.flags |= DGROUP_SPHERES_UNDER_CHAIN;
-        if (ptype == RT_PRIM_XY_RECT) G.n_xy++;
-        if (ptype == RT_PRIM_XZ_RECT) G.n_xz++;
-        if (ptype == RT_PRIM_YZ_RECT) G.n_yz++;
+        if (ptype == RT_PRIM_XY_RECT && tested) G.n_xy++;
+        if (ptype == RT_PRIM_XZ_RECT && tested) G.n_xz++;
+        if (ptype == RT_PRIM_YZ_RECT && tested) G.n_yz++;
         DPrim L = P;  // the record's copy: the primitive in its chain's space
         if (ptype == RT_PRIM_SPHERE) {
           for (int k = 0; k < 4; ++k) L.d[k] = pd[k];
@@ -1060,7 +1161,7 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
   // BVHs for the large groups, built on the device: surface-area sweep up to RT_SWEEP_MAX primitives,
   // Morton order beyond (or whichever builder the caller names)
   int n_bvh_nodes = 0;
-  auto group_size = [](const DGroup& G) { return G.n_xy + G.n_xz + G.n_yz + G.n_sph; };
+  auto group_size = [](const DGroup& G) { return G.n_xy + G.n_xz + G.n_yz + G.n_sph + G.n_lidbox; };
   for (auto& G : groups)
     if (group_size(G) > RT_BRUTE_MAX) n_bvh_nodes += group_size(G) - 1;
   DBvhNode* d_nodes = nullptr;

@@ -47,6 +47,8 @@ __host__ __device__ __forceinline__ void prim_box(const DPrim& P, float time_lo,
       b.mn[a] = (float)(fmin(c0[a], c1[a]) - r);
       b.mx[a] = (float)(fmax(c0[a], c1[a]) + r);
     }
+  } else if (type == RT_PRIM_LIDBOX) {
+    for (int a = 0; a < 3; ++a) { b.mn[a] = P.f[2 * a]; b.mx[a] = P.f[2 * a + 1]; }
   } else {
     int ia, ib, ic;
     if (type == RT_PRIM_XY_RECT) { ia = 0; ib = 1; ic = 2; }

@@ -392,6 +392,13 @@ RT_DEV bool wins_tie(int cand_type, int cand_idx, int best_type, int best_idx) {
   return !is_rect(best_type) && cand_idx < best_idx;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct BoxSlab;
+RT_DEV BoxSlab box_slab(const float* w, const RayX& r);
+RT_DEV bool open_box_accept(const BoxSlab& s, float pm, float tmin, float tmax, float& t);
+template <class X, class T>
+RT_DEV void test_lidbox(const DScene& S, int idx, const RayX& r, float tmin, Best& best, T& tally);
+
 // One primitive visited OUT of scan order (BVH leaves): explicit tie rule on the ranks.
 // `leaf` is what the tree stores: index | type << RT_LEAF_TYPE_SHIFT.
 template <class X, bool SURF = false, class T>
@@ -401,6 +408,10 @@ RT_DEV void test_prim_any_order(const DScene& S, int leaf, const RayX& r, float 
   const DPrim RT_CONST& P = prims[idx];
   float t;
   double root = 0.0;
+  if (type == RT_PRIM_LIDBOX) {
+    test_lidbox<X>(S, idx, r, tmin, best, tally);
+    return;
+  }
   if (is_rect(type)) {
     tally.template add<RT_EV_RECT_TEST>();
     // The orientation differs per lane here: select the ray's components. The copies are made
@@ -600,7 +611,6 @@ RT_DEV void bvh_traverse(const X& ctx, int root, const RayX& r, float tmin, Best
 // its comparison accepts; x - x is +0, so equality accepts, and a later rect wins an exact tie
 // with the closest-so-far. OR-ing the six sign bits replaces six compares. Slot 0 is tested before
 // slot 1 against the closest-so-far, as the reference's scan would.
-typedef float f2 __attribute__((ext_vector_type(2)));
 template <int TYPE>
 RT_DEV void rect_pair(f2 k, f2 a0, f2 a1, f2 b0, f2 b1, int i0, int i1, const RayX& r, float tmin, Best& best) {
   float oc, ic, oa, da, ob, db;
@@ -714,6 +724,43 @@ RT_DEV bool open_box_accept(const BoxSlab& s, float pm, float tmin, float tmax, 
   const int sgn = __float_as_int(s.tf - s.tn) | __float_as_int(t - tmin) | __float_as_int(tmax - t);
   return sgn >= 0 && (entry || s.tf != pm);
 }
+// A RT_PRIM_LIDBOX leaf (see rt_scene.h): the floor and the four walls as the slab test of a box whose y1 face is
+// missing, then the lid as the XZ rect it is. Both offers are made as the scan would make them, floor and walls
+// first, against the closest hit so far; a leaf is met out of scan order, so an exact tie with what is held goes by
+// the ranks of the rects (test_prim_any_order's rule), and the lid, later in the scan than the z faces and the
+// floor and earlier than the x faces, ties with them accordingly.
+template <class X, class T>
+RT_DEV void test_lidbox(const DScene& S, int idx, const RayX& r, float tmin, Best& best, T& tally) {
+  const DPrim RT_CONST* prims = cptr(S.prims);
+  const DPrim RT_CONST& P = prims[idx];
+  float w[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) w[q] = P.f[q];
+  const float lid_k = P.f[6];
+  const int f_z0 = __float_as_int(P.f[7]), f_z1 = __float_as_int(P.f[8]), f_y0 = __float_as_int(P.f[9]);
+  const int f_x0 = __float_as_int(P.f[10]), f_x1 = __float_as_int(P.f[11]), f_lid = __float_as_int(P.f[12]);
+  tally.template add<RT_EV_BOX_SLAB>();
+  const BoxSlab s = box_slab(w, r);
+  float t;
+  if (open_box_accept(s, s.ty.y, tmin, best.t, t)) {
+    // the face whose plane gave t; where two planes tie (an edge) the later one in scan order wins (z0 z1 y0 x0 x1)
+    int face = f_z0;
+    face = s.tz.y == t ? f_z1 : face;
+    face = s.ty.x == t ? f_y0 : face;
+    face = s.tx.x == t ? f_x0 : face;
+    face = s.tx.y == t ? f_x1 : face;
+    bool take = true;
+    if (t == best.t && best.prim >= 0) take = wins_tie(RT_PRIM_XY_RECT, face, prim_type(prims[best.prim].type), best.prim);
+    if (take) { best.t = t; best.prim = face; best.root = 0.0; }
+  }
+  tally.template add<RT_EV_RECT_TEST>();
+  if (rect_ok_axes(w[0], w[1], w[4], w[5], lid_k, r.o.y, r.inv.y, r.o.x, r.d.x, r.o.z, r.d.z, tmin, best.t, t)) {
+    bool take = true;
+    if (t == best.t && best.prim >= 0) take = wins_tie(RT_PRIM_XZ_RECT, f_lid, prim_type(prims[best.prim].type), best.prim);
+    if (take) { best.t = t; best.prim = f_lid; best.root = 0.0; }
+  }
+}
+
 template <class T>
 RT_DEV void brute_boxes(const float RT_CONST* B, int n_box, const RayX& r, float tmin, Best& best, T& tally) {
   for (int b = 0; b < n_box; ++b) {

@@ -14,6 +14,11 @@
 #define RT_LDS_NODE_MAX 1024
 #endif
 
+// Boxes with a sunk lid as single tree leaves (RT_PRIM_LIDBOX); 0 keeps their six rects as six leaves.
+#ifndef RT_LIDBOX_LEAVES
+#define RT_LIDBOX_LEAVES 1
+#endif
+
 namespace rt {
 
 size_t shade_lds_bytes(const DScene& S, int block);

@@ -67,6 +67,15 @@ struct DPrim {
   };
 };
 
+// A tree leaf that stands for the six rects of one box whose lid is sunk below its rim: box.clj:16-23 builds a box
+// as six rects and the ^long field k of rectangles.clj:9,46,83 drops the plane of every rect to a whole number, so a
+// box standing on y0 = 0 with a top at y1 = 37.4 has walls that reach 37.4 and a lid at y = 37 (the 400 ground boxes
+// of final-scene, scenes.clj:110-120). The walls and the floor are an axis-aligned box with the y1 face missing, the
+// lid is one XZ rect inside it. Internal to the device form (never in a description): DPrim.f = x0 x1 y0 y1 z0 z1,
+// lid k, then as int bits the device primitives of the faces z0 z1 y0 x0 x1 and of the lid. The six rects keep
+// their records behind the group's tested primitives; the leaf test only names the one that was hit.
+#define RT_PRIM_LIDBOX 5
+
 struct DChainOp {  // one wrapper of a chain, as the flattener keeps it on the host
   int32_t kind;
   float a, b, c;     // TRANSLATE: offset xyz | ROTATE_Y: sin, cos
@@ -116,6 +125,8 @@ struct DGroup {
   // pair records still hold and the number of boxes: xy | xz << 8 | yz << 16 | boxes << 24.
   int32_t loose;
   int32_t first_box;
+  int32_t n_lidbox;  // groups with a tree: RT_PRIM_LIDBOX leaves, stored behind the group's spheres
+  int32_t pad_[3];
 };
 struct DGroup64 {  // the same motion in FP64, for DGROUP_SPHERES_UNDER_CHAIN groups
   double rc, rs, bx, by, bz;
