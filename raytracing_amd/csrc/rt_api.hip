@@ -767,6 +767,7 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
             std::memcpy(&P.f[7 + k], &idx, 4);
           }
           G.n_lidbox++;
+          features |= F_LIDBOX;
           prims.push_back(P);
           prims_rec.push_back(P);
           continue;

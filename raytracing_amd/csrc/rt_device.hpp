@@ -394,7 +394,7 @@ RT_DEV bool wins_tie(int cand_type, int cand_idx, int best_type, int best_idx) {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 struct BoxSlab;
-RT_DEV BoxSlab box_slab(const float* w, const RayX& r);
+RT_DEV BoxSlab box_slab6(float x0, float x1, float y0, float y1, float z0, float z1, const RayX& r);
 RT_DEV bool open_box_accept(const BoxSlab& s, float pm, float tmin, float tmax, float& t);
 template <class X, class T>
 RT_DEV void test_lidbox(const DScene& S, int idx, const RayX& r, float tmin, Best& best, T& tally);
@@ -408,9 +408,11 @@ RT_DEV void test_prim_any_order(const DScene& S, int leaf, const RayX& r, float 
   const DPrim RT_CONST& P = prims[idx];
   float t;
   double root = 0.0;
-  if (type == RT_PRIM_LIDBOX) {
-    test_lidbox<X>(S, idx, r, tmin, best, tally);
-    return;
+  if constexpr (X::has(F_LIDBOX)) {
+    if (type == RT_PRIM_LIDBOX) {
+      test_lidbox<X>(S, idx, r, tmin, best, tally);
+      return;
+    }
   }
   if (is_rect(type)) {
     tally.template add<RT_EV_RECT_TEST>();
@@ -692,11 +694,13 @@ struct BoxSlab {
   float tn, tf;    // entry = max(near), exit = min(far)
 };
 // w = x0 x1 y0 y1 z0 z1 (wave-uniform)
-RT_DEV BoxSlab box_slab(const float* w, const RayX& r) {
+RT_DEV BoxSlab box_slab6(float x0, float x1, float y0, float y1, float z0, float z1, const RayX& r);
+RT_DEV BoxSlab box_slab(const float* w, const RayX& r) { return box_slab6(w[0], w[1], w[2], w[3], w[4], w[5], r); }
+RT_DEV BoxSlab box_slab6(float x0, float x1, float y0, float y1, float z0, float z1, const RayX& r) {
   BoxSlab s;
-  s.tx = ((f2){w[0], w[1]} - (f2){r.o.x, r.o.x}) * (f2){r.inv.x, r.inv.x};
-  s.ty = ((f2){w[2], w[3]} - (f2){r.o.y, r.o.y}) * (f2){r.inv.y, r.inv.y};
-  s.tz = ((f2){w[4], w[5]} - (f2){r.o.z, r.o.z}) * (f2){r.inv.z, r.inv.z};
+  s.tx = ((f2){x0, x1} - (f2){r.o.x, r.o.x}) * (f2){r.inv.x, r.inv.x};
+  s.ty = ((f2){y0, y1} - (f2){r.o.y, r.o.y}) * (f2){r.inv.y, r.inv.y};
+  s.tz = ((f2){z0, z1} - (f2){r.o.z, r.o.z}) * (f2){r.inv.z, r.inv.z};
   // fminf/fmaxf drop a NaN operand (0 * inf when the origin lies on a face's plane)
   const float nx = fminf(s.tx.x, s.tx.y), fx = fmaxf(s.tx.x, s.tx.y);
   const float ny = fminf(s.ty.x, s.ty.y), fy = fmaxf(s.ty.x, s.ty.y);
@@ -733,14 +737,12 @@ template <class X, class T>
 RT_DEV void test_lidbox(const DScene& S, int idx, const RayX& r, float tmin, Best& best, T& tally) {
   const DPrim RT_CONST* prims = cptr(S.prims);
   const DPrim RT_CONST& P = prims[idx];
-  float w[6];
-#pragma unroll
-  for (int q = 0; q < 6; ++q) w[q] = P.f[q];
+  const float x0 = P.f[0], x1 = P.f[1], y0 = P.f[2], y1 = P.f[3], z0 = P.f[4], z1 = P.f[5];
   const float lid_k = P.f[6];
   const int f_z0 = __float_as_int(P.f[7]), f_z1 = __float_as_int(P.f[8]), f_y0 = __float_as_int(P.f[9]);
   const int f_x0 = __float_as_int(P.f[10]), f_x1 = __float_as_int(P.f[11]), f_lid = __float_as_int(P.f[12]);
   tally.template add<RT_EV_BOX_SLAB>();
-  const BoxSlab s = box_slab(w, r);
+  const BoxSlab s = box_slab6(x0, x1, y0, y1, z0, z1, r);
   float t;
   if (open_box_accept(s, s.ty.y, tmin, best.t, t)) {
     // the face whose plane gave t; where two planes tie (an edge) the later one in scan order wins (z0 z1 y0 x0 x1)
@@ -754,7 +756,11 @@ RT_DEV void test_lidbox(const DScene& S, int idx, const RayX& r, float tmin, Bes
     if (take) { best.t = t; best.prim = face; best.root = 0.0; }
   }
   tally.template add<RT_EV_RECT_TEST>();
-  if (rect_ok_axes(w[0], w[1], w[4], w[5], lid_k, r.o.y, r.inv.y, r.o.x, r.d.x, r.o.z, r.d.z, tmin, best.t, t)) {
+  // (opaque copies, as in test_prim_any_order: beside that function's per-lane selects the optimiser would
+  // otherwise fetch the ray's components from a selected address and park the ray in scratch memory)
+  float ox = r.o.x, oy = r.o.y, oz = r.o.z, dx = r.d.x, dz = r.d.z, iy = r.inv.y;
+  asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz), "+v"(dx), "+v"(dz), "+v"(iy));
+  if (rect_ok_axes(x0, x1, z0, z1, lid_k, oy, iy, ox, dx, oz, dz, tmin, best.t, t)) {
     bool take = true;
     if (t == best.t && best.prim >= 0) take = wins_tie(RT_PRIM_XZ_RECT, f_lid, prim_type(prims[best.prim].type), best.prim);
     if (take) { best.t = t; best.prim = f_lid; best.root = 0.0; }
