@@ -288,14 +288,14 @@ int rt_hit_batch(rt_ctx* ctx, const rt_scene* scene, int32_t n, const float* ori
 /* The kernels are compiled once per feature set ("instantiation": 0 rects under chains,
  * 1 + constant media, 2 spheres and rects in plain lists with metal / dielectric / checker / image
  * textures, 3 the same with BVHs, 4 spheres and rects with Perlin noise, 5 everything the
- * reference's worlds use, 6 + media with arbitrary boundaries) and a world
+ * reference's worlds use, 6 + media with arbitrary boundaries, 7 spheres alone in trees, solid colours and checkers) and a world
  * renders on the smallest one that covers it. rt_scene_get_variants reports which one that is and
  * the bit mask of all that cover the world; rt_hit_batch_variant answers rt_hit_batch's question
  * with a chosen instantiation (RT_VARIANT_RENDER = the one the render uses, RT_VARIANT_GENERAL =
  * instantiation 6, which is what rt_hit_batch runs), so a test can show that every instantiation
  * returns the same records. An instantiation that does not cover the world is refused
  * (RT_ERR_UNSUPPORTED). */
-#define RT_N_VARIANTS 7
+#define RT_N_VARIANTS 8
 #define RT_VARIANT_GENERAL (-1)
 #define RT_VARIANT_RENDER (-2)
 int rt_scene_get_variants(const rt_scene* scene, int32_t* render_variant, uint32_t* covering_mask);

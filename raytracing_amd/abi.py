@@ -20,8 +20,8 @@ RT_FLAG_COUNTERS = 1
 RT_FLAG_POOL_PATHS = 2
 RT_SPLIT_TILES, RT_SPLIT_SAMPLES = 0, 1
 RT_BVH_DEFAULT, RT_BVH_DEVICE_SAH, RT_BVH_HOST_SAH, RT_BVH_DEVICE_LBVH = 0, 1, 2, 3
-RT_N_VARIANTS, RT_VARIANT_GENERAL, RT_VARIANT_RENDER = 7, -1, -2
-VARIANT_NAMES = ["V_RECT", "V_SMOKE", "V_LIST", "V_SPH", "V_NOISE", "V_ALL_DEEP", "V_FULL"]
+RT_N_VARIANTS, RT_VARIANT_GENERAL, RT_VARIANT_RENDER = 8, -1, -2
+VARIANT_NAMES = ["V_RECT", "V_SMOKE", "V_LIST", "V_SPH", "V_NOISE", "V_ALL_DEEP", "V_FULL", "V_BALLS"]
 
 RT_EVENT_NAMES = [
     "aabb_test", "sphere_test", "sphere_root", "sphere_record", "msphere_center", "rect_test",

@@ -781,6 +781,7 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
         P.mat = d->prim_mat[pi];
         const double* pd = d->prim_d + (size_t)pi * RT_PRIM_STRIDE;
         if (ptype <= RT_PRIM_MOVING_SPHERE) { features |= F_SPHERES; G.n_sph += tested ? 1 : 0; }
+        else features |= F_RECTS;
         if (ptype <= RT_PRIM_MOVING_SPHERE && chain != 0) G.flags |= DGROUP_SPHERES_UNDER_CHAIN;
         if (ptype == RT_PRIM_XY_RECT && tested) G.n_xy++;
         if (ptype == RT_PRIM_XZ_RECT && tested) G.n_xz++;
@@ -1483,7 +1484,7 @@ int rt_hit_batch_variant(rt_ctx* ctx, const rt_scene* sc, int32_t variant, int32
                          rt_hit* out) {
   if (!ctx || !sc || sc->ctx != ctx) return fail(RT_ERR_ARG, "ctx/scene is NULL or the scene belongs to another context");
   if (n < 0 || (n > 0 && (!orig3 || !dir3 || !out))) return fail(RT_ERR_ARG, "bad ray batch arguments");
-  if (variant == RT_VARIANT_GENERAL) variant = RT_N_VARIANTS - 1;
+  if (variant == RT_VARIANT_GENERAL) variant = 6;  // V_FULL, the instantiation that covers every world
   if (variant == RT_VARIANT_RENDER) variant = render_variant(sc->S);
   if (variant < 0 || variant >= RT_N_VARIANTS) return fail(RT_ERR_ARG, "unknown kernel instantiation %d", variant);
   if (!variant_covers(sc->S, variant))

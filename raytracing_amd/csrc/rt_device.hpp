@@ -241,6 +241,7 @@ template <uint32_t FEAT>
 struct Ctx {
   static constexpr uint32_t feat = FEAT;
   static constexpr bool has(uint32_t f) { return (FEAT & f) != 0; }
+  static constexpr bool rects() { return (FEAT & F_RECTS) != 0; }
   DScene S;
   const DPrimInfo RT_LDS* lds_info;    // F_SMALL: the scene's DPrimInfo table in LDS
   const DChainRec RT_LDS* lds_chains;  // F_SMALL: its chain records in LDS
@@ -414,7 +415,7 @@ RT_DEV void test_prim_any_order(const DScene& S, int leaf, const RayX& r, float 
       return;
     }
   }
-  if (is_rect(type)) {
+  if (X::rects() && is_rect(type)) {
     tally.template add<RT_EV_RECT_TEST>();
     // The orientation differs per lane here: select the ray's components. The copies are made
     // opaque first; selecting between loads of one struct would otherwise be rewritten into a
@@ -831,10 +832,12 @@ RT_DEV void brute_group_hit(const DScene& S, const DGroup RT_CONST& G, const Ray
   const DPrim RT_CONST* prims = cptr(S.prims);
   int first = G.first_prim;
   const int loose = G.loose;
+  if constexpr (X::rects()) {
   brute_rects<pair_batch<X>()>(cptr(S.brute_rects) + G.first_rect * RT_PAIR_STRIDE, loose & 255, (loose >> 8) & 255, (loose >> 16) & 255,
               r, tmin, best, tally);
   brute_boxes(cptr(S.brute_boxes) + G.first_box * RT_BOX_STRIDE, loose >> 24, r, tmin, best, tally);
   brute_open_boxes(cptr(S.brute_boxes) + (G.first_box + (loose >> 24)) * RT_BOX_STRIDE, (G.flags >> DGROUP_OPEN_SHIFT) & 255, r, tmin, best, tally);
+  }
   first += G.n_xy + G.n_xz + G.n_yz;
   if constexpr (X::has(F_SPHERES)) {
     const int n_sph = G.n_sph;
@@ -925,7 +928,7 @@ RT_DEV void prim_record(const DScene& S, int prim, const DPrimInfo& I, const Ray
   rec.rgb = mk(I.r, I.g, I.b); rec.mx = I.x;
   rec.t = t;
   rec.u = rec.v = 0.f;
-  if (!X::has(F_SPHERES) || is_rect(type)) {
+  if (!X::has(F_SPHERES) || (X::rects() && is_rect(type))) {
     // rectangles.clj:31-37; the in-plane point is o + t d, the constant coordinate is set to k
     // (in FP64 the reference's o + t d lands on k to 1e-13; FP32 rounding would not).
     tally.template add<RT_EV_RECT_RECORD>();

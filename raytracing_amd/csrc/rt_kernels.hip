@@ -21,6 +21,9 @@
 #ifndef RT_WAVES_SPH
 #define RT_WAVES_SPH 5
 #endif
+#ifndef RT_WAVES_BALLS
+#define RT_WAVES_BALLS 5
+#endif
 #ifndef RT_WAVES_ALL
 #define RT_WAVES_ALL 4
 #endif
@@ -185,6 +188,7 @@ constexpr int waves_per_simd(uint32_t feat, bool count) {
   // spheres in plain lists: at 5 / 6 / 7 / 8 waves the earth takes 22.5 / 21.2 / 21.0 / 22.6 ms (23.5 on the
   // kernel that also walks trees), the two checkered spheres 73.3 / 70.0 / 69.8 / 75.1 (75.9)
   if ((feat & F_SPHERES) && !(feat & (F_BVH | F_NOISE | F_MEDIA | F_CHAINS))) return count ? 2 : RT_WAVES_LIST;
+  if ((feat & F_BVH) && !(feat & F_RECTS)) return count ? 2 : RT_WAVES_BALLS;
   if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : RT_WAVES_SPH;
   // the smoke worlds' kernel spills at 72 and at 80 registers: five waves measured 5 % faster than seven
   if (feat & F_MEDIA) return count ? 4 : RT_WAVES_SMOKE;
@@ -692,11 +696,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_sample_batch(DScene S, DCamera cam
 //            spheres, the lit Perlin sphere)
 //   V_ALL    everything the reference's worlds use (V_ALL_DEEP: the instantiation that renders it)
 //   V_FULL   + media whose boundary is any hittable (V_ALL answers one-sphere and one-box boundaries)
-constexpr uint32_t V_RECT = F_CHAINS | F_SMALL;
-constexpr uint32_t V_SMOKE = F_CHAINS | F_MEDIA | F_SMALL;
-constexpr uint32_t V_LIST = F_SPHERES | F_SPECULAR | F_TEXTURES | F_IMAGE;
+//   V_BALLS  spheres alone, in trees, solid colours and checkers: no rect tests or records, no image textures (the random-spheres world)
+constexpr uint32_t V_RECT = F_CHAINS | F_SMALL | F_RECTS;
+constexpr uint32_t V_SMOKE = F_CHAINS | F_MEDIA | F_SMALL | F_RECTS;
+constexpr uint32_t V_LIST = F_SPHERES | F_SPECULAR | F_TEXTURES | F_IMAGE | F_RECTS;
+constexpr uint32_t V_BALLS = F_SPHERES | F_SPECULAR | F_BVH | F_TEXTURES;
 constexpr uint32_t V_SPH = V_LIST | F_BVH;
-constexpr uint32_t V_NOISE = F_SPHERES | F_TEXTURES | F_NOISE;
+constexpr uint32_t V_NOISE = F_SPHERES | F_TEXTURES | F_NOISE | F_RECTS;
 constexpr uint32_t V_ALL = F_ALL;
 constexpr uint32_t V_ALL_DEEP = F_ALL | F_DEEP;  // everything, for worlds with BVHs
 constexpr uint32_t V_FULL = F_ALL | F_MEDIA_ANY;
@@ -704,6 +710,7 @@ constexpr uint32_t V_FULL = F_ALL | F_MEDIA_ANY;
 int pick_variant(const DScene& S) {
   const bool small = S.n_prims <= RT_LDS_PRIMS && S.n_chains <= RT_LDS_CHAINS;
   if (S.features & F_MEDIA_ANY) return 6;
+  if ((S.features & F_BVH) && (S.features & ~V_BALLS) == 0) return 7;
   if (small && (S.features & ~V_RECT) == 0) return 0;
   if (small && (S.features & ~V_SMOKE) == 0) return 1;
   if ((S.features & ~V_LIST) == 0) return 2;
@@ -759,7 +766,9 @@ auto with_render_kernel(const DScene& S, bool count, F&& f) {
     case 10: return f(k_render<V_ALL_DEEP, false>);
     case 11: return f(k_render<V_ALL, true>);
     case 12: return f(k_render<V_FULL, false>);
-    default: return f(k_render<V_FULL, true>);
+    case 13: return f(k_render<V_FULL, true>);
+    case 14: return f(k_render<V_BALLS, false>);
+    default: return f(k_render<V_BALLS, true>);
   }
 }
 
@@ -771,7 +780,7 @@ hipError_t allow_lds(size_t bytes) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   };
 #define RT_ALLOW(MASK) allow(k_render<MASK, false>); allow(k_render<MASK, true>); allow(k_hit_batch<MASK>); allow(k_sample_batch<MASK>); allow(k_scatter_batch<MASK>);
-  RT_ALLOW(V_RECT) RT_ALLOW(V_SMOKE) RT_ALLOW(V_LIST) RT_ALLOW(V_SPH) RT_ALLOW(V_NOISE) RT_ALLOW(V_FULL)
+  RT_ALLOW(V_RECT) RT_ALLOW(V_SMOKE) RT_ALLOW(V_LIST) RT_ALLOW(V_SPH) RT_ALLOW(V_NOISE) RT_ALLOW(V_FULL) RT_ALLOW(V_BALLS)
 #undef RT_ALLOW
   allow(k_render<V_ALL_DEEP, false>); allow(k_render<V_ALL, true>); allow(k_hit_batch<V_ALL_DEEP>);
   allow(k_sample_batch<V_ALL>); allow(k_scatter_batch<V_ALL>);
@@ -832,7 +841,7 @@ hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t*
 // Does instantiation `variant` (0 V_RECT .. 6 V_FULL) support everything the scene needs?
 bool variant_covers(const DScene& S, int variant) {
   const bool small = S.n_prims <= RT_LDS_PRIMS && S.n_chains <= RT_LDS_CHAINS;
-  const uint32_t masks[RT_N_VARIANTS] = {V_RECT, V_SMOKE, V_LIST, V_SPH, V_NOISE, V_ALL_DEEP, V_FULL};
+  const uint32_t masks[RT_N_VARIANTS] = {V_RECT, V_SMOKE, V_LIST, V_SPH, V_NOISE, V_ALL_DEEP, V_FULL, V_BALLS};
   if (variant < 0 || variant >= RT_N_VARIANTS) return false;
   if ((masks[variant] & F_SMALL) && !small) return false;
   return (S.features & ~masks[variant]) == 0;
@@ -853,6 +862,7 @@ hipError_t launch_hit_batch(const DScene& S, int variant, int n, const float* or
     RT_HIT_CASE(3, V_SPH)
     RT_HIT_CASE(4, V_NOISE)
     RT_HIT_CASE(5, V_ALL_DEEP)
+    RT_HIT_CASE(7, V_BALLS)
     default: hipLaunchKernelGGL(k_hit_batch<V_FULL>, grid, block, lds, stream, S, n, orig3, dir3, time, tmin, tmax, medium_xi, out); break;
   }
 #undef RT_HIT_CASE
@@ -873,6 +883,7 @@ hipError_t launch_scatter_batch(const DScene& S, uint32_t seed_lo, uint32_t seed
     RT_SC_CASE(3, V_SPH)
     RT_SC_CASE(4, V_NOISE)
     RT_SC_CASE(6, V_FULL)
+    RT_SC_CASE(7, V_BALLS)
     default: hipLaunchKernelGGL(k_scatter_batch<V_ALL>, grid, block, lds, stream, S, seed_lo, seed_hi, n, orig3, dir3, time, px, smp, bounce, out); break;
   }
 #undef RT_SC_CASE
@@ -891,6 +902,7 @@ hipError_t launch_sample_batch(const DScene& S, const DCamera& cam, const DRende
     case 3: hipLaunchKernelGGL(k_sample_batch<V_SPH>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     case 4: hipLaunchKernelGGL(k_sample_batch<V_NOISE>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     case 6: hipLaunchKernelGGL(k_sample_batch<V_FULL>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
+    case 7: hipLaunchKernelGGL(k_sample_batch<V_BALLS>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
     default: hipLaunchKernelGGL(k_sample_batch<V_ALL>, grid, block, lds, stream, S, cam, R, n, px, smp, out_rgb); break;
   }
   return hipGetLastError();

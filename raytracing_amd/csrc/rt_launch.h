@@ -34,9 +34,9 @@ size_t pool_lds_bytes(const DScene& S, int block);
 hipError_t launch_resolve(const DRender& R, const float* partial, float* rgb_sum, uint32_t* argb,
                           hipStream_t stream);
 hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t* argb, hipStream_t stream);
-// Instantiations of the kernels: 0 V_RECT, 1 V_SMOKE, 2 V_LIST, 3 V_SPH, 4 V_NOISE, 5 V_ALL_DEEP, 6 V_FULL.
+// Instantiations of the kernels: 0 V_RECT, 1 V_SMOKE, 2 V_LIST, 3 V_SPH, 4 V_NOISE, 5 V_ALL_DEEP, 6 V_FULL, 7 V_BALLS.
 #ifndef RT_N_VARIANTS
-#define RT_N_VARIANTS 7
+#define RT_N_VARIANTS 8
 #endif
 bool variant_covers(const DScene& S, int variant);
 int render_variant(const DScene& S);

@@ -30,5 +30,5 @@ for r, d in zip(rows, demangle):
     d = re.sub(r"\(rt::RenderArgs\)|\(.*\)$", "", d)[:70]
     print(f"{d:70s} {r.get('VGPRs', '?'):>6s} {r.get('AGPRs', '?'):>6s} {r.get('SGPRs', r.get('TotalSGPRs', '?')):>6s} {r.get('VGPRs Spill', '?'):>10s} {r.get('SGPRs Spill', '?'):>10s} "
           f"{r.get('ScratchSize [bytes/lane]', '?'):>14s} {r.get('Occupancy [waves/SIMD]', '?'):>10s} {r.get('LDS Size [bytes/block]', '?'):>10s}")
-print("\n(k_render<F, false> instantiations by mask: 72 = V_RECT, 76 = V_SMOKE, 305 = V_LIST, 307 = V_SPH, 145 = V_NOISE, 3007 = V_ALL_DEEP, 3519 = V_FULL; 2495 = V_ALL, the counting build of V_ALL_DEEP and the parity hooks;"
+print("\n(k_render<F, false> instantiations by mask: 72 = V_RECT, 76 = V_SMOKE, 35 = V_BALLS (see rt_kernels.hip for the other masks), the counting build of V_ALL_DEEP and the parity hooks;"
       "\n dynamic LDS is asked for at launch and is not in the last column: rt_scene_get_info().lds_bytes)")
