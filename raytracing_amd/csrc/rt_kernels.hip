@@ -22,7 +22,7 @@
 #define RT_WAVES_SPH 5
 #endif
 #ifndef RT_WAVES_BALLS
-#define RT_WAVES_BALLS 5
+#define RT_WAVES_BALLS 6
 #endif
 #ifndef RT_WAVES_ALL
 #define RT_WAVES_ALL 4
@@ -188,6 +188,8 @@ constexpr int waves_per_simd(uint32_t feat, bool count) {
   // spheres in plain lists: at 5 / 6 / 7 / 8 waves the earth takes 22.5 / 21.2 / 21.0 / 22.6 ms (23.5 on the
   // kernel that also walks trees), the two checkered spheres 73.3 / 70.0 / 69.8 / 75.1 (75.9)
   if ((feat & F_SPHERES) && !(feat & (F_BVH | F_NOISE | F_MEDIA | F_CHAINS))) return count ? 2 : RT_WAVES_LIST;
+  // spheres alone: 96 registers at five waves, 80 at six, nothing spilled either way; 4 / 5 / 6 waves render the
+  // random-spheres world in 67.5 / 62.4 / 60.5 ms (a seventh workgroup per CU does not fit its LDS)
   if ((feat & F_BVH) && !(feat & F_RECTS)) return count ? 2 : RT_WAVES_BALLS;
   if (feat & (F_SPHERES | F_BVH | F_TEXTURES)) return count ? 2 : RT_WAVES_SPH;
   // the smoke worlds' kernel spills at 72 and at 80 registers: five waves measured 5 % faster than seven
