@@ -1210,6 +1210,7 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
   S.n_bvh_nodes = n_bvh_nodes;
   // the second half of every packed node also lives in LDS when the trees are small enough for that not to
   // cost the kernel a resident workgroup (16 bytes per node and workgroup)
+  S.xch_on_stacks = S.bvh_stack >= 4 ? 1 : 0;  // (256 words per wave = four levels of its 64 lanes' stacks)
   S.lds_nodes = n_bvh_nodes <= RT_LDS_NODE_MAX ? n_bvh_nodes : 0;
   {
     std::vector<int32_t> bvh_next(groups.size(), -1);

@@ -185,7 +185,11 @@ RT_DEV float lane_pull(float v, uint32_t src_lane) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
 }
 template <class T>
-RT_DEV V3 wave_random_in_unit_sphere(bool need, const Rng& g, uint32_t bounce, uint32_t RT_LDS* xch, T& tally) {
+RT_DEV V3 wave_random_in_unit_sphere(bool need, const Rng& g, uint32_t bounce, uint32_t RT_LDS* xch0, uint32_t xs, T& tally) {
+  // entry e of the exchange area: four words at (e / 16) * xs + (e % 16) * 4. xs = 64 is an area of its own, 1 KiB in
+  // one piece; kernels that walk trees lay the area over the first four levels of the wave's own traversal stacks
+  // (idle while the wave draws), whose levels lie xs = blockDim words apart.
+  auto entry = [&](uint32_t e) { return xch0 + (e >> 4) * xs + (e & 15u) * 4u; };
   const uint32_t lane = wave_lane();
   uint32_t o[4];
   philox(g, 0, bounce, P_SPHERE, o);
@@ -202,14 +206,16 @@ RT_DEV V3 wave_random_in_unit_sphere(bool need, const Rng& g, uint32_t bounce, u
     const uint32_t h = 1u << k;
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(unlucky >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)unlucky, 0u));
     if (!found) {
-      xch[rank * 4 + 0] = g.k0; xch[rank * 4 + 1] = g.k1; xch[rank * 4 + 2] = bounce; xch[rank * 4 + 3] = next_blk;
+      uint32_t RT_LDS* xch = entry(rank);
+      xch[0] = g.k0; xch[1] = g.k1; xch[2] = bounce; xch[3] = next_blk;
     }
     const uint32_t slot = lane >> k;
     const bool helper = slot < n;
     const uint32_t rs = helper ? slot : 0u;
-    Rng hg{xch[rs * 4 + 0], xch[rs * 4 + 1], g.s0, g.s1};
-    const uint32_t hb = xch[rs * 4 + 2];
-    const uint32_t blk = xch[rs * 4 + 3] + (lane & (h - 1u));
+    const uint32_t RT_LDS* xr = entry(rs);
+    Rng hg{xr[0], xr[1], g.s0, g.s1};
+    const uint32_t hb = xr[2];
+    const uint32_t blk = xr[3] + (lane & (h - 1u));
     philox(hg, blk, hb, P_SPHERE, o);
     v0 = cube_point(o[0], o[1]); v1 = cube_point(o[2], o[3]);
     ok0 = len2(v0) >= 1.0f; ok1 = len2(v1) >= 1.0f;
@@ -248,6 +254,7 @@ struct Ctx {
   const float* lds_perlin_vec;      // n_perlin * 1024 floats (LDS)
   const uint8_t* lds_perlin_perm;   // n_perlin * 768 bytes (LDS)
   uint32_t RT_LDS* lds_xch;         // this wave's 1 KiB exchange area (wave_random_in_unit_sphere)
+  uint32_t xch_stride;              // ... and how its 16-entry rows are spaced (see there)
   int* lds_stack;                   // BVH stack base of this lane (stride = blockDim.x)
   int stack_stride;
   typedef uint32_t node_q __attribute__((ext_vector_type(4)));

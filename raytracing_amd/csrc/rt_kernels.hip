@@ -55,7 +55,8 @@ namespace rt {
 //   [0, n_perlin*4096)                 Perlin gradient vectors, float4 each
 //   [.., + n_perlin*768 rounded to 16) Perlin permutations, bytes
 //   [.., + n_prims*96 + n_chains*64)   DPrimInfo and DChainRec tables (F_SMALL instantiations only)
-//   [.., + blockDim/64 * 1024)         one exchange area per wave (wave_random_in_unit_sphere)
+//   [.., + blockDim/64 * 1024)         one exchange area per wave (wave_random_in_unit_sphere); kernels that walk trees
+//                                      whose stacks have four levels or more lay it over those instead (xch_on_stacks)
 //   [.., + blockDim*bvh_stack*4)       per-lane BVH stacks, entry e of lane l at e*blockDim + l
 //   [.., + lds_nodes*16)               the second half of every packed tree node (instantiations that walk trees,
 //                                      when the scene's trees fit: DScene::lds_nodes)
@@ -91,8 +92,12 @@ __device__ __forceinline__ Ctx<FEAT> make_ctx(const DScene& S, unsigned char* ld
   if constexpr ((FEAT & (F_NOISE | F_SMALL)) != 0) __syncthreads();
   X.lds_perlin_vec = reinterpret_cast<const float*>(lv);
   X.lds_perlin_perm = lp;
-  X.lds_xch = (uint32_t RT_LDS*)(lds + vec_bytes + perm_bytes + info_bytes) + (threadIdx.x >> 6) * 256;
-  const size_t xch_bytes = (size_t)(blockDim.x >> 6) * 1024;
+  // (scene-uniform) kernels that walk trees lay the exchange area over their traversal stacks
+  const bool xch_on_stacks = (FEAT & F_BVH) != 0 && S.xch_on_stacks != 0;
+  const size_t xch_bytes = xch_on_stacks ? 0 : (size_t)(blockDim.x >> 6) * 1024;
+  X.lds_xch = xch_on_stacks ? (uint32_t RT_LDS*)(lds + vec_bytes + perm_bytes + info_bytes) + (threadIdx.x >> 6) * 64
+                            : (uint32_t RT_LDS*)(lds + vec_bytes + perm_bytes + info_bytes) + (threadIdx.x >> 6) * 256;
+  X.xch_stride = xch_on_stacks ? blockDim.x : 64u;
   X.lds_stack = reinterpret_cast<int*>(lds + vec_bytes + perm_bytes + info_bytes + xch_bytes) + threadIdx.x;
   X.stack_stride = blockDim.x;
   X.lds_node_half = nullptr;
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       ++waited;
       if (n_pending >= RT_SHADE_MIN || !can_look || waited >= RT_SHADE_WAIT) {  // wave-uniform
         waited = 0;
-        const V3 sv = wave_random_in_unit_sphere(pending && needs_sphere_draw(held.mtype), g, bounce, X.lds_xch, tally);
+        const V3 sv = wave_random_in_unit_sphere(pending && needs_sphere_draw(held.mtype), g, bounce, X.lds_xch, X.xch_stride, tally);
         if (pending) {
           V3 L;
           if (path_finish<true>(X, R, true, held, sv, ray, beta, bounce, g, L, tally)) {
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       RT_STAMP(ts3);
       // The bounce's random-in-unit-sphere vectors, drawn by the whole wave together. (Drawing
       // before the hit record is built, while fewer registers are live, measured slower.)
-      const V3 sv = wave_random_in_unit_sphere(active && hit && needs_sphere_draw(rec.mtype), g, bounce, X.lds_xch, tally);
+      const V3 sv = wave_random_in_unit_sphere(active && hit && needs_sphere_draw(rec.mtype), g, bounce, X.lds_xch, X.xch_stride, tally);
       if (active) {
         V3 L;
         if (path_finish<true>(X, R, hit, rec, sv, ray, beta, bounce, g, L, tally)) {
@@ -726,7 +731,9 @@ size_t variant_lds_bytes(const DScene& S, int block, int variant) {
   size_t perm_bytes = ((size_t)S.n_perlin * 768 + 15) & ~(size_t)15;
   size_t info_bytes = variant < 2 ? (size_t)S.n_prims * sizeof(DPrimInfo) + (size_t)S.n_chains * sizeof(DChainRec) : 0;
   const size_t node_bytes = (variant == 3 || variant >= 5) ? (size_t)S.lds_nodes * 16 : 0;
-  return vec_bytes + perm_bytes + info_bytes + (size_t)(block / 64) * 1024 + (size_t)block * (size_t)S.bvh_stack * 4 + node_bytes;
+  const bool walks = variant == 3 || variant >= 5;
+  const size_t xch_bytes = (walks && S.xch_on_stacks) ? 0 : (size_t)(block / 64) * 1024;
+  return vec_bytes + perm_bytes + info_bytes + xch_bytes + (size_t)block * (size_t)S.bvh_stack * 4 + node_bytes;
 }
 size_t shade_lds_bytes(const DScene& S, int block) { return variant_lds_bytes(S, block, pick_variant(S)); }
 
@@ -800,6 +807,7 @@ hipError_t launch_render(const DScene& S, const DCamera& cam, const DRender& R, 
       RenderArgs A;
       A.S = S; A.cam = cam; A.R = R; A.out = out; A.queue = queue; A.stats = stats;
       A.S.lds_nodes = 0;  // the pool has its own LDS layout and its own walk
+      A.S.xch_on_stacks = 0;
       hipLaunchKernelGGL(kernel, dim3(grid), dim3(RT_BLOCK), lds, stream, A);
       return hipGetLastError();
     });

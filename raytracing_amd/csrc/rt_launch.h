@@ -11,7 +11,7 @@
 
 // Trees of up to this many nodes keep the second half of each packed node in LDS (see bvh_traverse).
 #ifndef RT_LDS_NODE_MAX
-#define RT_LDS_NODE_MAX 1024
+#define RT_LDS_NODE_MAX 1280
 #endif
 
 // Boxes with a sunk lid as single tree leaves (RT_PRIM_LIDBOX); 0 keeps their six rects as six leaves.

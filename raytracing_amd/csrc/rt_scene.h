@@ -246,6 +246,7 @@ struct DScene {
   const int32_t* bvh_next;       // per group: the next surface group after it that has a tree, or -1
   int32_t first_bvh_group;       // the first surface group with a tree, or -1
   int32_t n_bvh_nodes;
+  int32_t xch_on_stacks;         // 1 when the kernels that walk trees lay their exchange area over the traversal stacks
   int32_t lds_nodes;             // n_bvh_nodes when the kernels that walk trees keep the nodes' second halves in LDS, else 0
   uint32_t features;             // F_* mask of what this scene needs from a kernel instantiation
 };
