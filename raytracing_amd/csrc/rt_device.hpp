@@ -184,12 +184,14 @@ RT_DEV uint32_t wave_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_am
 RT_DEV float lane_pull(float v, uint32_t src_lane) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
 }
-template <class T>
+template <bool ROWS = false, class T>
 RT_DEV V3 wave_random_in_unit_sphere(bool need, const Rng& g, uint32_t bounce, uint32_t RT_LDS* xch0, uint32_t xs, T& tally) {
   // entry e of the exchange area: four words at (e / 16) * xs + (e % 16) * 4. xs = 64 is an area of its own, 1 KiB in
   // one piece; kernels that walk trees lay the area over the first four levels of the wave's own traversal stacks
   // (idle while the wave draws), whose levels lie xs = blockDim words apart.
-  auto entry = [&](uint32_t e) { return xch0 + (e >> 4) * xs + (e & 15u) * 4u; };
+  // (ROWS = false: the area in one piece, xs not looked at — the form the kernels without trees compile, whose
+  // issue slots are all taken: the general form costs the Cornell box 0.9 %)
+  auto entry = [&](uint32_t e) { return ROWS ? xch0 + (e >> 4) * xs + (e & 15u) * 4u : xch0 + e * 4u; };
   const uint32_t lane = wave_lane();
   uint32_t o[4];
   philox(g, 0, bounce, P_SPHERE, o);

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       ++waited;
       if (n_pending >= RT_SHADE_MIN || !can_look || waited >= RT_SHADE_WAIT) {  // wave-uniform
         waited = 0;
-        const V3 sv = wave_random_in_unit_sphere(pending && needs_sphere_draw(held.mtype), g, bounce, X.lds_xch, X.xch_stride, tally);
+        const V3 sv = wave_random_in_unit_sphere<(FEAT & F_BVH) != 0>(pending && needs_sphere_draw(held.mtype), g, bounce, X.lds_xch, X.xch_stride, tally);
         if (pending) {
           V3 L;
           if (path_finish<true>(X, R, true, held, sv, ray, beta, bounce, g, L, tally)) {
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
       RT_STAMP(ts3);
       // The bounce's random-in-unit-sphere vectors, drawn by the whole wave together. (Drawing
       // before the hit record is built, while fewer registers are live, measured slower.)
-      const V3 sv = wave_random_in_unit_sphere(active && hit && needs_sphere_draw(rec.mtype), g, bounce, X.lds_xch, X.xch_stride, tally);
+      const V3 sv = wave_random_in_unit_sphere<(FEAT & F_BVH) != 0>(active && hit && needs_sphere_draw(rec.mtype), g, bounce, X.lds_xch, X.xch_stride, tally);
       if (active) {
         V3 L;
         if (path_finish<true>(X, R, hit, rec, sv, ray, beta, bounce, g, L, tally)) {

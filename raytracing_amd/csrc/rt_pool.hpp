@@ -457,7 +457,7 @@ __global__ __launch_bounds__(RT_BLOCK, 2) void k_render_pool(RenderArgs A) {
       rec.mtype = -1;
       if (hit) hit_record(X, ray, best, false, rec, tally);
       V3 sv = mk(0.f, 0.f, 0.f);
-      if constexpr (wave_draw(FEAT)) sv = wave_random_in_unit_sphere(hit && needs_sphere_draw(rec.mtype), g, bounce, X.lds_xch, X.xch_stride, tally);
+      if constexpr (wave_draw(FEAT)) sv = wave_random_in_unit_sphere(hit && needs_sphere_draw(rec.mtype), g, bounce, X.lds_xch, X.xch_stride, tally);  // (its area is in one piece)
       if (mine) {
         V3 L;
         if (path_finish<wave_draw(FEAT)>(X, R, hit, rec, sv, ray, beta, bounce, g, L, tally)) {
