@@ -34,9 +34,9 @@ class _PyRng:  # the two calls texture.perlin makes
 PROFILES = {  # what a world may contain -> the instantiation it should land on
     "any": None,
     "rect": dict(shapes=(2, 3, 4, 5), mats=(0, 8), wrap=3, media=(1,), want=("V_RECT", "V_SMOKE", "V_ALL_DEEP")),
-    "list": dict(shapes=(0, 1, 2, 3, 4), mats=(0, 5, 6, 7, 8, 9, 10), wrap=0, media=(), want=("V_LIST", "V_SPH")),
+    "list": dict(shapes=(0, 1, 2, 3, 4), mats=(0, 5, 6, 7, 8, 9, 10), wrap=0, media=(), want=("V_LIST", "V_SPH", "V_BALLS")),
     "noise": dict(shapes=(0, 2, 3, 4), mats=(0, 8, 9, 11), wrap=0, media=(), want=("V_NOISE", "V_LIST", "V_RECT")),
-    # big lists below wrappers: trees under instance chains (spheres there take the FP64 ray transform)
+    # big lists below wrappers: trees under instance chains (rects there are met in the chain's space, spheres in world space)
     "instanced": dict(shapes=(0, 1, 2, 3, 4, 5), mats=None, wrap=3, media=(0, 1), want=None, lists=(18, 70)),
 }
 
