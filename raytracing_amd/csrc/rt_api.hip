@@ -794,6 +794,7 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
           for (int k = 0; k < 9; ++k) L.d[k] = pd[k];
           sphere_fields(e, P.d);
           any_moving = true;
+          features |= F_MOVING;
           tlo = std::min(tlo, std::min(pd[6], pd[7]));
           thi = std::max(thi, std::max(pd[6], pd[7]));
         } else {

@@ -308,11 +308,11 @@ RT_DEV D3 rayx_d64(const RayX& r) {
   else return mkd((double)r.d.x + (double)r.d_lo.x, (double)r.d.y + (double)r.d_lo.y, (double)r.d.z + (double)r.d_lo.z);
 }
 // How an instantiation intersects spheres (template argument of sphere_roots / sphere_t).
-enum { SPH_ONE_RCP = 1, SPH_LO = 2 };
+enum { SPH_ONE_RCP = 1, SPH_LO = 2, SPH_STATIC = 4 };  // SPH_STATIC: the world has no moving sphere
 // SURF: the ray of a surface group. Those never hold spheres below a chain (the host carries such spheres into world
 // space), so their rays have no residuals: six registers fewer across a walk and six FP64 additions fewer per sphere.
 template <class X, bool SURF = false>
-constexpr int sphere_mode() { return SPH_ONE_RCP | ((X::has(F_CHAINS) && !SURF) ? SPH_LO : 0); }
+constexpr int sphere_mode() { return SPH_ONE_RCP | ((X::has(F_CHAINS) && !SURF) ? SPH_LO : 0) | (X::has(F_MOVING) ? 0 : SPH_STATIC); }
 
 // rectangles.clj:20-30 (XY), :57-67 (XZ), :94-104 (YZ): t from the constant axis, reject iff
 // t < t-min or t > t-max (so equality with the closest-so-far is accepted and a later rect
@@ -329,16 +329,16 @@ RT_DEV bool rect_ok_axes(float a0, float a1, float b0, float b1, float k, float 
   return !(m > 0.0f);
 }
 
-template <class PRIM>
+template <bool STATIC = false, class PRIM>
 RT_DEV D3 sphere_center(const PRIM& P, int type, float tm) {
-  if (type == RT_PRIM_SPHERE) return mkd(P.d[0], P.d[1], P.d[2]);
+  if (STATIC || type == RT_PRIM_SPHERE) return mkd(P.d[0], P.d[1], P.d[2]);
   // base.clj:298-302
   double k = ((double)tm - P.d[6]) / (P.d[7] - P.d[6]);
   return mkd(P.d[0] + (P.d[3] - P.d[0]) * k, P.d[1] + (P.d[4] - P.d[1]) * k,
              P.d[2] + (P.d[5] - P.d[2]) * k);
 }
-template <class PRIM>
-RT_DEV double sphere_radius(const PRIM& P, int type) { return type == RT_PRIM_SPHERE ? P.d[3] : P.d[8]; }
+template <bool STATIC = false, class PRIM>
+RT_DEV double sphere_radius(const PRIM& P, int type) { return (STATIC || type == RT_PRIM_SPHERE) ? P.d[3] : P.d[8]; }
 
 // n / d in FP64, correctly rounded, given r = RN(1/d) (Markstein): q = RN(n r), then one FMA
 // residual and one FMA correction. Three instructions instead of the ~12 of a full division;
@@ -358,8 +358,8 @@ RT_DEV double exact_div(double n, double d, double r) {
 template <int MODE, class PRIM, class T>
 RT_DEV bool sphere_roots(const PRIM& P, int type, const RayX& r, double& root1, double& root2, T& tally) {
   if (type == RT_PRIM_MOVING_SPHERE) tally.template add<RT_EV_MSPHERE_CENTER>();
-  D3 c = sphere_center(P, type, r.tm);
-  double radius = sphere_radius(P, type);
+  D3 c = sphere_center<(MODE & SPH_STATIC) != 0>(P, type, r.tm);
+  double radius = sphere_radius<(MODE & SPH_STATIC) != 0>(P, type);
   D3 o = rayx_o64<(MODE & SPH_LO) != 0>(r), d = rayx_d64<(MODE & SPH_LO) != 0>(r);
   D3 oc = mkd(o.x - c.x, o.y - c.y, o.z - c.z);
   double a = ddot(d, d);
@@ -963,8 +963,8 @@ RT_DEV void prim_record(const DScene& S, int prim, const DPrimInfo& I, const Ray
       // base.clj:243-246 in FP64 from the FP64 root the winning test kept
       tally.template add<RT_EV_SPHERE_RECORD>();
       const DPrim RT_CONST& P = cptr(S.prims_rec)[prim];
-      D3 c = sphere_center(P, type, r.tm);
-      double inv_r = 1.0 / sphere_radius(P, type);
+      D3 c = sphere_center<!X::has(F_MOVING)>(P, type, r.tm);
+      double inv_r = 1.0 / sphere_radius<!X::has(F_MOVING)>(P, type);
       D3 o64 = rayx_o64<X::has(F_CHAINS)>(r), d64 = rayx_d64<X::has(F_CHAINS)>(r);
       D3 pd = mkd(fma(root, d64.x, o64.x), fma(root, d64.y, o64.y), fma(root, d64.z, o64.z));
       D3 out = mkd((pd.x - c.x) * inv_r, (pd.y - c.y) * inv_r, (pd.z - c.z) * inv_r);

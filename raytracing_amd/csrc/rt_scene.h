@@ -54,7 +54,8 @@ enum : uint32_t {
                     // leaf test's extra branch costs the sphere / BVH kernel 11 % on the random-spheres world)
   F_RECTS = 4096,   // rect primitives (every instantiation but the one for worlds of spheres alone: without the rect
                     // tests and records the sphere / BVH kernel spills nothing and is 8 % faster on the random-spheres world)
-  F_ALL = 63 | 128 | 256 | 2048 | 4096,
+  F_MOVING = 8192,  // moving spheres (every instantiation but the one for worlds of static spheres alone)
+  F_ALL = 63 | 128 | 256 | 2048 | 4096 | 8192,
   F_DEEP = 512,     // not a scene feature: same code, compiled for more waves per SIMD (BVH worlds)
   F_MEDIA_ANY = 1024  // some medium's boundary is neither one sphere nor one closed box: its two boundary
                       // queries run the general group loops (30 more registers in every kernel that has them)
