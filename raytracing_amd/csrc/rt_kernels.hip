@@ -207,7 +207,8 @@ constexpr int waves_per_simd(uint32_t feat, bool count) {
 // Which instantiations draw the bounce's random-in-unit-sphere vectors with the whole wave
 // (wave_random_in_unit_sphere) instead of a rejection loop per lane. Measured: the all-features
 // kernels +1 to +3 % (it used to cost them registers they did not have), the sphere/BVH kernel
-// -8 % (random-scene) and -20 % (two-spheres).
+// -8 % (random-scene) and -20 % (two-spheres), the list kernel -12 % (earth) and -7 % (two-spheres) at six
+// waves per SIMD and -29 % at its own seven.
 #ifndef RT_WAVE_DRAW_ALL
 #define RT_WAVE_DRAW_ALL 1
 #endif
