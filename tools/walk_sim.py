@@ -100,6 +100,7 @@ def hit_prim(i, o, d, tmin, tmax):
             if n @ d > 0: n = -n
             return root, n
     return None
+PRIM_WEIGHT = {}  # what a primitive counts in "prim tests" (the last section counts a ground box's six rects as one test)
 def trace(nodes, root, items, o, d):
     with np.errstate(divide='ignore'):
         inv = 1.0 / d
@@ -113,7 +114,7 @@ def trace(nodes, root, items, o, d):
         if l == -1:
             leaves += 1
             for p in items[r][2]:
-                leaf_prims += 1
+                leaf_prims += PRIM_WEIGHT.get(p, 1.0)
                 h = hit_prim(p, o, d, 1e-3, tmax)
                 if h: tmax = h[0]; best = h
             if not stack: break
@@ -170,3 +171,66 @@ for K in (1, 2, 3, 4):
         x = a[rng.permutation(len(a))[:n]].reshape(-1, 53, K).sum(2).max(1)
         tot.append(x.mean() / K)
     print("paths per lane", K, "walk steps per wave per ray-slot", np.mean(tot))
+
+# ---- leaves of more than one primitive, priced on the tree the library walks now: one leaf per ground box, the light,
+# the loose spheres and the thousand r = 10 spheres in world space (scenes.clj:132,144-146). A node whose two children
+# are leaves becomes one leaf of both primitives (then of up to four): fewer steps, dearer leaf rounds.
+th = math.radians(15.0)
+small = [i for i in range(len(pt)) if pt[i] == 0 and abs(pd[i, 3]) == 10.]
+def small_box(i):
+    x, y, z = pd[i, :3]
+    c = np.array([math.cos(th) * x + math.sin(th) * z - 100., y + 270., -math.sin(th) * x + math.cos(th) * z + 395.])
+    return list(c - 10.), list(c + 10.), c
+world_c = {i: small_box(i)[2] for i in small}
+_hit_prim = hit_prim
+def hit_prim(i, o, d, tmin, tmax):  # the small spheres are tested where they stand in the world
+    if i in world_c:
+        c = world_c[i]; oc = o - c
+        a = d @ d; hb = oc @ d; cc = oc @ oc - 100.; disc = hb * hb - a * cc
+        if disc < 0: return None
+        sq = math.sqrt(disc)
+        for root in ((-hb - sq) / a, (-hb + sq) / a):
+            if tmin < root < tmax:
+                n = (o + root * d - c) / 10.
+                if n @ d > 0: n = -n
+                return root, n
+        return None
+    return _hit_prim(i, o, d, tmin, tmax)
+def collapse(nodes, items, limit, only_spheres):
+    nodes = list(nodes); items = list(items)
+    for n, nd in enumerate(nodes):
+        lo, hi, l, r = nd
+        if l == -1 or nodes[l][2] != -1 or nodes[r][2] != -1: continue
+        pl = items[nodes[l][3]][2]; pr = items[nodes[r][3]][2]
+        if len(pl) + len(pr) > limit: continue
+        if only_spheres and any(pt[p] != 0 for p in pl + pr): continue
+        items.append((lo, hi, pl + pr)); nodes[n] = (lo, hi, -1, len(items) - 1)
+    return nodes, items
+t0 = time.time()
+full = items_B(True) + [(small_box(i)[:2] + ([i],)) for i in small]
+nodes1, root1 = build(full)
+print(f"\nwhole world: {len(full)} leaves, {len(nodes1)} nodes {time.time()-t0:.1f}s", flush=True)
+pool2 = []
+while len(pool2) < 6000:
+    o, d = cam_ray(rng.integers(0, W), rng.integers(0, H))
+    for b in range(8):
+        pool2.append((o, d))
+        h, *_ = trace(nodes1, root1, full, o, d)
+        if h is None: break
+        o = o + h[0] * d; d = h[1] + rand_unit()
+PRIM_WEIGHT.update({i: 1.0 / 6.0 for i in ground})
+variants = {"one primitive per leaf": (nodes1, full)}
+n2, i2 = collapse(nodes1, full, 2, True); variants["pairs of spheres"] = (n2, i2)
+n2a, i2a = collapse(nodes1, full, 2, False); variants["pairs of anything"] = (n2a, i2a)
+n4, i4 = collapse(n2a, i2a, 4, False); variants["up to four"] = (n4, i4)
+# a leaf round of one primitive costs about 1.6 steps of the walk (in-kernel stamps: 1.2 k cycles a step, 1.9 k a round);
+# each further primitive of a round is priced at one more step
+idx = rng.permutation(len(pool2))[: (len(pool2) // 53) * 53].reshape(-1, 53)  # the same waves for every variant
+for name, (nd, it) in variants.items():
+    a = np.array([trace(nd, root1, it, o, d)[1:] for o, d in pool2])
+    st = a[:, 0][idx].max(1).mean(); lv = a[:, 1][idx].max(1).mean()
+    per_round = a[:, 2].sum() / max(a[:, 1].sum(), 1)
+    cost = st + lv * (1.6 + (per_round - 1.0))
+    print(f"{name:24s} steps/ray {a[:,0].mean():5.2f} wave-max {st:5.2f}  leaf rounds wave-max {lv:4.2f}  tests per leaf visit {per_round:4.2f}"
+          f"  priced {cost:5.1f} step-units per wave-iteration")
+print(f"{time.time()-t0:.1f}s")
