@@ -2,7 +2,8 @@
 """Headline benchmark: Cornell box 1024x1024 @ 1000 spp (the configuration the headline metric is quoted on), Msamples/s.
 
 A step = one complete render of that workload: every rank renders its tile shard (rank r owns
-the 8x8 tiles t with t % N == r), the per-GPU FP32 accumulators are summed onto rank 0 with one
+one 8x8 tile of every N consecutive ones, the place moving on by one per tile row), the per-GPU
+FP32 accumulators are summed onto rank 0 with one
 RCCL reduce and rank 0 packs the pixels. Inputs (the uploaded world, the camera) are resident in
 HBM before the timed region. Total work is fixed as N grows (strong scaling).
 

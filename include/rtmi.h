@@ -150,8 +150,11 @@ typedef struct rt_params {
   int32_t spp;            /* samples rendered by THIS call per pixel                      */
   int32_t sample_offset;  /* global index of this call's first sample (sample slicing)   */
   int32_t max_depth;      /* core.clj:58 (50)                                             */
-  int32_t shard_index;    /* this call renders the 8x8-pixel tiles t with                 */
-  int32_t shard_count;    /*   t % shard_count == shard_index (row-major tile order)      */
+  int32_t shard_index;    /* this call renders one 8x8-pixel tile of every group of       */
+  int32_t shard_count;    /*   shard_count consecutive tiles (row-major tile order): tile */
+                          /*   t belongs to shard (t % n + n - turn) % n, n = shard_count, */
+                          /*   turn = ((t / n) * n / tiles_per_row) % n: the deal moves on */
+                          /*   by one place per tile row, so no shard owns fixed columns   */
   int32_t flags;          /* RT_FLAG_*                                                    */
   double  background[3];  /* core.clj:30,60-65                                            */
   uint64_t seed;

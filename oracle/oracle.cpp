@@ -673,7 +673,9 @@ bool tile_owned(const rt_params& p, int x, int y) {
   int tiles_x = (p.width + 7) / 8;
   int t = (y / 8) * tiles_x + (x / 8);
   int sc = p.shard_count > 0 ? p.shard_count : 1;
-  return t % sc == p.shard_index;
+  // the tiles are dealt in groups of sc; the deal moves on by one place with every tile row the groups start in
+  int turn = ((t / sc) * sc / tiles_x) % sc;
+  return (t % sc + sc - turn) % sc == p.shard_index;
 }
 
 }  // namespace

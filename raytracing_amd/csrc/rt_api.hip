@@ -350,7 +350,11 @@ int fill_render(const rt_scene* sc, const rt_camera* cam, const rt_params* p, DR
   R.tiles_x = (p->width + RT_TILE - 1) / RT_TILE;
   R.tiles_y = (p->height + RT_TILE - 1) / RT_TILE;
   int n_tiles = R.tiles_x * R.tiles_y;
-  R.n_owned_tiles = n_tiles > R.shard_index ? (n_tiles - R.shard_index + sc_count - 1) / sc_count : 0;
+  // every full group of sc_count tiles holds one tile of this shard; the last, partial group may (shard_tile)
+  {
+    const int full = n_tiles / sc_count;
+    R.n_owned_tiles = full + (shard_tile(full, R.shard_index, sc_count, R.tiles_x) < n_tiles ? 1 : 0);
+  }
   // A pixel's samples are split into work items ("chunks") by a schedule that depends on spp
   // alone, so the FP32 summation order of a pixel does not depend on how the image is sharded.
   // 64 equal chunks carry 80 % of the samples, then five tiers shrink down to single samples. The

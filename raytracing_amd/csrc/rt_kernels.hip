@@ -382,7 +382,7 @@ __global__ __launch_bounds__(RT_BLOCK, waves_per_simd(FEAT, COUNT)) void k_rende
           const uint32_t c = base / items_per_chunk;
           const uint32_t rem = base - c * items_per_chunk;
           const int tiles_x = C->R.tiles_x;
-          const int tile = C->R.shard_index + (int)(rem >> 6) * C->R.shard_count;
+          const int tile = shard_tile((int)(rem >> 6), C->R.shard_index, C->R.shard_count, tiles_x);
           q_tx0 = (tile % tiles_x) * RT_TILE;
           q_ty0 = (tile / tiles_x) * RT_TILE;
           q_s0 = C->R.chunk_start[c];
@@ -580,7 +580,7 @@ __global__ void k_resolve(DRender R, const float* __restrict__ partial, float* _
   int x = pix % R.width, y = pix / R.width;
   int tile = (y / RT_TILE) * R.tiles_x + (x / RT_TILE);
   float r = 0.f, g = 0.f, b = 0.f;
-  if (tile % R.shard_count == R.shard_index) {
+  if (tile_shard(tile, R.shard_count, R.tiles_x) == R.shard_index) {
     // the slab is indexed by work item: chunk, then owned tile, then place in the tile
     const size_t items_per_chunk = (size_t)R.n_owned_tiles * 64;
     const size_t in_chunk = (size_t)(tile / R.shard_count) * 64 + (size_t)((y % RT_TILE) * RT_TILE + x % RT_TILE);

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(RT_BLOCK, 2) void k_render_pool(RenderArgs A) {
             const uint32_t c = base / items_per_chunk;
             const uint32_t rem = base - c * items_per_chunk;
             const int tiles_x = C->R.tiles_x;
-            const int tile = C->R.shard_index + (int)(rem >> 6) * C->R.shard_count;
+            const int tile = shard_tile((int)(rem >> 6), C->R.shard_index, C->R.shard_count, tiles_x);
             q_tx0 = (tile % tiles_x) * RT_TILE;
             q_ty0 = (tile / tiles_x) * RT_TILE;
             q_s0 = C->R.chunk_start[c];

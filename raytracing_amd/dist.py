@@ -2,8 +2,9 @@
 
 The sample loop shards naturally: every (pixel, sample) is independent and its random stream is
 keyed by (pixel, sample), so any split reproduces the same per-sample radiance. Two splits:
-  * "tile":   rank r renders the 8x8 tiles t with t % world == r (all samples); pixels are
-              disjoint, so summing the zero-filled full frames is a gather.
+  * "tile":   rank r renders one 8x8 tile of every group of `world` consecutive tiles (all samples;
+              the place within the group moves on by one per tile row, see rt_params in rtmi.h);
+              pixels are disjoint, so summing the zero-filled full frames is a gather.
   * "sample": rank r renders a contiguous slice of the samples for every pixel.
 Either way the only exchange is one reduce(sum) of the W*H*3 FP32 accumulators to rank 0,
 which then applies the pixel post-process (reference core.clj:106-108,118,121-122).

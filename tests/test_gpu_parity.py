@@ -385,9 +385,13 @@ def test_tile_sharding_is_bit_exact_and_sample_slices_add_up(gpu_ctx):
             part, _, s = sc.render(cam, abi.make_params(W, H, spp, 50, cfg["background"], seed=3,
                                                         shard_index=idx, shard_count=count))
             owned = np.zeros((H, W), dtype=bool)
+            tiles_x = (W + 7) // 8
             for y in range(H):
-                for x in range(W):
-                    owned[y, x] = ((y // 8) * ((W + 7) // 8) + x // 8) % count == idx
+                for x in range(W):   # rt_params in rtmi.h: the deal of a group's tiles moves on by one per tile row
+                    t = (y // 8) * tiles_x + x // 8
+                    turn = ((t // count) * count // tiles_x) % count
+                    owned[y, x] = (t % count + count - turn) % count == idx
+            assert owned.any() or count > tiles_x * ((H + 7) // 8)
             assert (part[~owned] == 0).all()
             acc += part
             rays += s["rays"]
