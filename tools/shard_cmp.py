@@ -13,7 +13,12 @@ sc = ctx.scene(flat)
 def run(**kw):
     p = abi.make_params(1024, 1024, kw.pop("spp"), 50, cfg["background"], seed=0x5EED0001, **kw)
     sc.render_device(cam, p, 0, 0, want_stats=True)
-    return min(sc.render_device(cam, p, 0, 0, want_stats=True)["kernel_ms"] for _ in range(3))
+    st = [sc.render_device(cam, p, 0, 0, want_stats=True) for _ in range(3)]
+    mhz.append(min(s["shader_mhz"] for s in st))
+    return min(s["kernel_ms"] for s in st)
+
+
+mhz = []  # the shader clock each launch measured in itself (lowest of the three), in the order of the runs
 
 
 full = run(spp=1000)
@@ -24,3 +29,4 @@ for n in (2, 4, 8):
           f" ms; slowest {max(ms):.3f} = {full / n / max(ms):.3f} of the whole frame's rate", flush=True)
     s = run(spp=1000 // n)
     print(f"sample slice of {1000 // n} spp: {s:.3f} ms = {full / n / s:.3f}", flush=True)
+print("shader MHz per run: " + " ".join(f"{m:.0f}" for m in mhz))
