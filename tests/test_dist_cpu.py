@@ -105,3 +105,40 @@ def test_more_ranks_than_samples_contributes_zeros():
 
     acc = render_distributed(render_fn, base, rank=0, world=2, mode="sample", reduce_fn=lambda t: None)
     assert calls == [1] and float(acc.abs().sum()) == 0.0
+
+
+def tile_shard(x, y, width, count):
+    """Which shard renders pixel (x, y): the rule of rt_params in include/rtmi.h."""
+    tiles_x = (width + 7) // 8
+    t = (y // 8) * tiles_x + x // 8
+    turn = ((t // count) * count // tiles_x) % count
+    return (t % count + count - turn) % count
+
+
+@pytest.mark.parametrize("w,h", [(40, 24), (9, 33), (130, 17), (1, 1)])
+def test_tile_shards_partition_the_frame_by_the_documented_rule(w, h):
+    """The CPU restatement's tile shards: each renders exactly the pixels the rule gives it (zeros elsewhere), their
+    sum is the whole frame bit for bit, and over a frame of many tile rows no shard keeps a fixed tile column."""
+    from oracle import binding as ob
+    cfg, flat = setup("cornell-box", scene_seed=1)
+    cam = build_camera(cfg, w / h)
+
+    def frame(**kw):
+        p = abi.make_params(w, h, 2, 50, cfg["background"], seed=SEED, **kw)
+        rgb, _, _ = ob.render(flat, cam, p, nthreads=1, want_argb=False)
+        return np.ascontiguousarray(rgb, dtype=np.float32).reshape(h, w, 3)
+
+    full = frame()
+    ys, xs = np.mgrid[0:h, 0:w]
+    for count in (2, 3, 8):
+        owner = np.vectorize(lambda x, y: tile_shard(x, y, w, count))(xs, ys)
+        acc = np.zeros_like(full)
+        for idx in range(count):
+            part = frame(shard_index=idx, shard_count=count)
+            assert (part[owner != idx] == 0).all()
+            assert np.array_equal(part[owner == idx], full[owner == idx])
+            acc += part
+        assert np.array_equal(acc, full)
+    # 128 tiles per row, eight shards: the column a shard owns moves on from one tile row to the next
+    cols = {tuple(x for x in range(0, 64, 8) if tile_shard(x, y, 1024, 8) == 0) for y in range(0, 64, 8)}
+    assert len(cols) == 8
