@@ -328,6 +328,14 @@ void fill_camera(const rt_camera* c, const rt_params* p, DCamera& o) {
     o.u[a] = c->u[a]; o.v[a] = c->v[a];
   }
   o.lens_radius = c->lens_radius; o.time0 = c->time0; o.time1 = c->time1;
+  o.pinhole = (c->lens_radius == 0.0 && p->width > 1 && p->height > 1) ? 1 : 0;
+  for (int a = 0; a < 3; ++a) {
+    o.dC[a] = c->lower_left_corner[a] - c->origin[a];
+    o.dH[a] = c->horizontal[a] / o.wm1;
+    o.dV[a] = c->vertical[a] / o.hm1;
+    o.fO[a] = (float)c->origin[a];
+  }
+  o.pad_ = 0;
 }
 
 int fill_render(const rt_scene* sc, const rt_camera* cam, const rt_params* p, DRender& R) {

@@ -115,8 +115,13 @@ struct Rng {
 };
 
 RT_DEV void philox(const Rng& g, uint32_t blk, uint32_t bounce, uint32_t purpose, uint32_t out[4]) {
+#ifdef RT_KEY_SEED
+  uint32_t c0 = g.k0, c1 = g.k1, c2 = blk, c3 = (bounce << 4) | purpose;
+  uint32_t k0 = g.s0, k1 = g.s1;
+#else
   uint32_t c0 = blk, c1 = (bounce << 4) | purpose, c2 = g.s0, c3 = g.s1;
   uint32_t k0 = g.k0, k1 = g.k1;
+#endif
 #pragma unroll
   for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
     // one 32x32->64 multiply per word pair (v_mad_u64_u32)
@@ -175,7 +180,7 @@ RT_DEV V3 random_unit_vector(const Rng& g, uint32_t bounce, T& tally) {  // base
 // bounce, against one needed per lane on average) with most lanes idle. Here every lane first
 // tries its own block 0; the lanes still without a vector (27 %) then publish their key in LDS and
 // the WHOLE wave works for them: lane l evaluates block next + (l mod h) of the (l / h)-th
-// unlucky lane, h = 16, 8, 4, 2 or 1 helpers each, so one more block time covers 2h further
+// unlucky lane, h = 16 down to 1 helpers each (as many as 64 lanes allow), so one more block time covers 2h further
 // candidates per unlucky lane. A ballot tells each unlucky lane which of its helpers accepted first
 // (helpers are in block order, the two candidates of a block in order: the reference's first
 // accepted draw) and it pulls that vector across lanes.
@@ -204,30 +209,41 @@ RT_DEV V3 wave_random_in_unit_sphere(bool need, const Rng& g, uint32_t bounce, u
   unsigned long long unlucky = __ballot(!found);
   while (unlucky != 0ull) {  // wave-uniform
     const uint32_t n = (uint32_t)__popcll(unlucky);
-    const uint32_t k = n <= 4 ? 4u : n <= 8 ? 3u : n <= 16 ? 2u : n <= 32 ? 1u : 0u;  // log2(helpers each)
-    const uint32_t h = 1u << k;
+    // helpers each: as many as 64 lanes allow, not only powers of two (17 to 21 unlucky lanes get three helpers
+    // each, six candidates, where two would leave one lane in thirteen for a further round); hm = ceil(2^16 / h),
+    // so that lane / h = (lane * hm) >> 16 for every lane below 64
+    uint32_t h, hm;
+    if (n <= 4) { h = 16u; hm = 4096u; }
+    else if (n <= 8) { h = 8u; hm = 8192u; }
+    else if (n <= 9) { h = 7u; hm = 9363u; }
+    else if (n <= 10) { h = 6u; hm = 10923u; }
+    else if (n <= 12) { h = 5u; hm = 13108u; }
+    else if (n <= 16) { h = 4u; hm = 16384u; }
+    else if (n <= 21) { h = 3u; hm = 21846u; }
+    else if (n <= 32) { h = 2u; hm = 32768u; }
+    else { h = 1u; hm = 65536u; }
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(unlucky >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)unlucky, 0u));
     if (!found) {
       uint32_t RT_LDS* xch = entry(rank);
       xch[0] = g.k0; xch[1] = g.k1; xch[2] = bounce; xch[3] = next_blk;
     }
-    const uint32_t slot = lane >> k;
+    const uint32_t slot = (lane * hm) >> 16;
     const bool helper = slot < n;
     const uint32_t rs = helper ? slot : 0u;
     const uint32_t RT_LDS* xr = entry(rs);
     Rng hg{xr[0], xr[1], g.s0, g.s1};
     const uint32_t hb = xr[2];
-    const uint32_t blk = xr[3] + (lane & (h - 1u));
+    const uint32_t blk = xr[3] + (lane - slot * h);
     philox(hg, blk, hb, P_SPHERE, o);
     v0 = cube_point(o[0], o[1]); v1 = cube_point(o[2], o[3]);
     ok0 = len2(v0) >= 1.0f; ok1 = len2(v1) >= 1.0f;
     const V3 hv = ok0 ? v0 : v1;
     const unsigned long long accepted = __ballot(helper && (ok0 || ok1) && blk < RT_MAX_TRIALS / 2);
     // this lane's helpers are lanes [rank * h, rank * h + h): the lowest set bit is the first accepted block
-    const uint32_t bits = (uint32_t)(accepted >> ((rank << k) & 63u)) & ((1u << h) - 1u);
+    const uint32_t bits = (uint32_t)(accepted >> ((rank * h) & 63u)) & ((1u << h) - 1u);
     const bool got = !found && bits != 0u;
     const uint32_t first = (uint32_t)__builtin_ctz(bits | 0x10000u);
-    const uint32_t src = ((rank << k) + first) & 63u;
+    const uint32_t src = (rank * h + first) & 63u;
     const float px = lane_pull(hv.x, src), py = lane_pull(hv.y, src), pz = lane_pull(hv.z, src);
     if constexpr (T::on) {
       const int first_cand = __builtin_amdgcn_ds_bpermute((int)(src << 2), ok0 ? 1 : 2);
@@ -1454,6 +1470,16 @@ RT_DEV Ray camera_ray(CAMP camp, int x, int y, const Rng& g, T& tally) {
   tally.template add<RT_EV_CAMERA_RAY>();
   uint32_t o4[4];
   philox(g, 0, 0, P_CAM, o4);
+  if (cam.pinhole) {  // wave-uniform
+    const double U = 5.9604644775390625e-8;  // 2^-24
+    const double sx = fma((double)(o4[0] >> 8), U, (double)x), ty = fma((double)(o4[1] >> 8), U, (double)y);
+    Ray r;
+    r.o = mk(cam.fO[0], cam.fO[1], cam.fO[2]);
+    r.d = mk((float)fma(cam.dV[0], ty, fma(cam.dH[0], sx, cam.dC[0])), (float)fma(cam.dV[1], ty, fma(cam.dH[1], sx, cam.dC[1])),
+             (float)fma(cam.dV[2], ty, fma(cam.dH[2], sx, cam.dC[2])));
+    r.tm = (float)fma(cam.time1 - cam.time0, (double)u24(o4[2]), cam.time0);
+    return r;
+  }
   double s = exact_div((double)x + (double)u24(o4[0]), cam.wm1, cam.inv_wm1);
   double t = exact_div((double)y + (double)u24(o4[1]), cam.hm1, cam.inv_hm1);
   double time_ = fma(cam.time1 - cam.time0, (double)u24(o4[2]), cam.time0);
@@ -1477,11 +1503,22 @@ RT_DEV Ray camera_ray(CAMP camp, int x, int y, const Rng& g, T& tally) {
     ry = dy * cam.lens_radius;
   }
   double off[3], org[3], dir[3];
+  if (cam.lens_radius != 0.0) {
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    off[a] = fma(cam.u[a], rx, cam.v[a] * ry);
-    org[a] = cam.origin[a] + off[a];
-    dir[a] = (fma(cam.vertical[a], t, fma(cam.horizontal[a], s, cam.llc[a])) - cam.origin[a]) - off[a];
+    for (int a = 0; a < 3; ++a) {
+      off[a] = fma(cam.u[a], rx, cam.v[a] * ry);
+      org[a] = cam.origin[a] + off[a];
+      dir[a] = (fma(cam.vertical[a], t, fma(cam.horizontal[a], s, cam.llc[a])) - cam.origin[a]) - off[a];
+    }
+  } else {
+    // a pinhole (ray.clj:18-21 with lens-radius 0): the offset is u * 0 + v * 0 = +0, or -0 where an axis component
+    // of u or v is negative; origin + (+-0) is the origin and x - (+-0) is x, unless x itself is a zero: the sign of
+    // a zero direction component is not observable in what follows (its reciprocal is clamped, products with it are 0)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      org[a] = cam.origin[a];
+      dir[a] = fma(cam.vertical[a], t, fma(cam.horizontal[a], s, cam.llc[a])) - cam.origin[a];
+    }
   }
   Ray r;
   r.o = mk((float)org[0], (float)org[1], (float)org[2]);

@@ -258,6 +258,15 @@ struct DCamera {  // the reference's camera map in FP64 (camera.clj:24-33)
   // core.clj:99,101 divide the jittered pixel coordinate by W-1 and H-1: the divisors and their
   // correctly rounded reciprocals, for an exact division in three FMAs (see camera_ray)
   double wm1, hm1, inv_wm1, inv_hm1;
+  // A pinhole camera (lens radius 0, the setting of seven of the reference's eight worlds, core.clj:60-65) on an image
+  // of at least 2 x 2 pixels: dir = dC + (x + jitter) dH + (y + jitter) dV with dC = llc - origin,
+  // dH = horizontal / (W - 1), dV = vertical / (H - 1): two FP64 FMAs per axis instead of two exact divisions and the
+  // lens terms. Against ray.clj:21-25 evaluated in FP64 this re-associates at the 1e-16 level, which the rounding of
+  // the ray to FP32 hides (the two agree in all but about one ray in 1e8).
+  double dC[3], dH[3], dV[3];
+  float fO[3];
+  int32_t pinhole;
+  int32_t pad_;
 };
 
 struct DRender {

@@ -17,7 +17,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 kernel = sys.argv[1] if len(sys.argv) > 1 else "k_renderILj72ELb0"
 asm = "/tmp/rt_kernels_marks.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fno-gpu-rdc",
-                       "-DRT_PHASE_MARKS", "--cuda-device-only", "-S", os.path.join(ROOT, "raytracing_amd", "csrc", "rt_kernels.hip"), "-o", asm],
+                       "-DRT_PHASE_MARKS", *os.environ.get("RT_EXTRA_FLAGS", "").split(), "--cuda-device-only", "-S", os.path.join(ROOT, "raytracing_amd", "csrc", "rt_kernels.hip"), "-o", asm],
                       stderr=subprocess.DEVNULL)
 lines = open(asm).read().split("\n")
 start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN2rt\w*%s\w*:" % kernel, l))
