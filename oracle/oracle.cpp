@@ -109,7 +109,8 @@ struct Rng {
   const double* script = nullptr;
   int script_n = 0, script_pos = 0;
   bool script_overrun = false;
-  // Keyed back end.
+  // Keyed back end: a draw is Philox(counter = (pixel index, sample index, block, bounce << 4 | purpose),
+  // key = (seed_lo, seed_hi)). `key` holds what names the path, the pixel and the sample index.
   uint32_t key[2] = {0, 0};
   uint32_t seed_lo = 0, seed_hi = 0;
   // Scripted per-medium uniforms (the rt_hit_batch parity hook); NULL = not used.
@@ -124,8 +125,9 @@ struct Rng {
     return script[script_pos++];
   }
   void block(int purpose, int bounce, uint32_t blk, uint32_t out[4]) const {
-    uint32_t ctr[4] = {blk, ((uint32_t)bounce << 4) | (uint32_t)purpose, seed_lo, seed_hi};
-    philox4x32(ctr, key, out);
+    uint32_t ctr[4] = {key[0], key[1], blk, ((uint32_t)bounce << 4) | (uint32_t)purpose};
+    uint32_t seed[2] = {seed_lo, seed_hi};
+    philox4x32(ctr, seed, out);
   }
   // (rand) (rand) at core.clj:99,101, then (random-double time0 time1)'s uniform at ray.clj:26.
   void camera(double& jx, double& jy) {

@@ -101,9 +101,11 @@ struct Tally<true> {
 // Philox-4x32 (Salmon et al., SC'11) with 7 rounds, the fewest the paper reports Crush-resistant:
 // its 32x32->64 multiplies are the most expensive VALU instructions of the whole path loop. A draw
 // is addressed, not sequenced:
-//   key     = (pixel index y*W+x, global sample index)
-//   counter = (block, bounce << 4 | purpose, seed_lo, seed_hi)
-// so its value does not depend on evaluation order or on which GPU runs the sample.
+//   key     = (seed_lo, seed_hi)
+//   counter = (pixel index y*W+x, global sample index, block, bounce << 4 | purpose)
+// so its value does not depend on evaluation order or on which GPU runs the sample. The key is the same
+// for every lane: its schedule (two additions per round) runs on the scalar unit, and a lane's own
+// block 0 has one multiplicand of its first round known at compile time.
 // Uniforms are the top 24 bits / 2^24 (21-bit fields for the unit-sphere candidates): exactly
 // representable in FP32 and FP64.
 enum { P_CAM = 0, P_DISK = 1, P_SPHERE = 2, P_DIEL = 3, P_MEDIUM = 4 };
@@ -111,17 +113,12 @@ enum { P_CAM = 0, P_DISK = 1, P_SPHERE = 2, P_DIEL = 3, P_MEDIUM = 4 };
 #define RT_PHILOX_ROUNDS 7
 
 struct Rng {
-  uint32_t k0, k1, s0, s1;
+  uint32_t k0, k1, s0, s1;  // k0, k1: the pixel and sample words of the counter (per lane); s0, s1: the key (the seed)
 };
 
 RT_DEV void philox(const Rng& g, uint32_t blk, uint32_t bounce, uint32_t purpose, uint32_t out[4]) {
-#ifdef RT_KEY_SEED
   uint32_t c0 = g.k0, c1 = g.k1, c2 = blk, c3 = (bounce << 4) | purpose;
   uint32_t k0 = g.s0, k1 = g.s1;
-#else
-  uint32_t c0 = blk, c1 = (bounce << 4) | purpose, c2 = g.s0, c3 = g.s1;
-  uint32_t k0 = g.k0, k1 = g.k1;
-#endif
 #pragma unroll
   for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
     // one 32x32->64 multiply per word pair (v_mad_u64_u32)

@@ -32,9 +32,9 @@ def probe_rays(cfg, n, seed):
 
 def medium_uniform(seed, px, smp, bounce, m):
     """The keyed uniform of medium m at ray-color invocation `bounce` (same addressing as the
-    device and the oracle): Philox-4x32-7, counter (m>>2, bounce<<4|4, seed), key (px, smp)."""
+    device and the oracle): Philox-4x32-7, counter (px, smp, m>>2, bounce<<4|4), key (seed lo, seed hi)."""
     from oracle import binding as ob
-    o = ob.philox([m >> 2, (bounce << 4) | 4, seed & 0xFFFFFFFF, seed >> 32], [px, smp])
+    o = ob.philox([px, smp, m >> 2, (bounce << 4) | 4], [seed & 0xFFFFFFFF, seed >> 32])
     return (o[m & 3] >> 8) / 16777216.0
 
 
@@ -83,9 +83,9 @@ def philox4x32(ctr, key, rounds=7):
 
 def keyed_camera_ray(cam, W, H, px, smp, seed):
     """core.clj:96-102 + ray.clj:14-26 in FP64 for pixel index px, sample smp, lens radius 0: the
-    jitter uniforms are words 0..2 of the keyed block (counter (0, 0, seed lo, seed hi), key (px,
-    smp)), top 24 bits each. -> (orig[3], dir[3], time)."""
-    w = philox4x32([0, 0, seed & _MASK, seed >> 32], [px, smp])
+    jitter uniforms are words 0..2 of the keyed block (counter (px, smp, 0, 0), key (seed lo,
+    seed hi)), top 24 bits each. -> (orig[3], dir[3], time)."""
+    w = philox4x32([px, smp, 0, 0], [seed & _MASK, seed >> 32])
     u = [(x >> 8) / 16777216.0 for x in w]
     x, y = px % W, px // W
     s, t = (x + u[0]) / (W - 1), (y + u[1]) / (H - 1)
