@@ -25,7 +25,7 @@ import torch.distributed as dist  # noqa: E402
 
 from raytracing_amd import abi, lib  # noqa: E402
 from raytracing_amd.core import build_camera, setup  # noqa: E402
-from raytracing_amd.dist import render_distributed  # noqa: E402
+from raytracing_amd.dist import render_distributed, shard_params as dist_shard_params  # noqa: E402
 
 # Algorithmic FLOPs per event of the path kernel (add/sub/mul/div/sqrt/min/max/abs/floor and each
 # transcendental = 1, FMA = 2; compares, selects, integer and RNG work = 0), following the
@@ -92,11 +92,19 @@ def measure_config(ctx, device, scene_name, W, H, spp, peak):
     samples = W * H * spp
     achieved = fps * samples / (st["kernel_ms"] * 1e-3) / 1e12
     pm = pmc_record(scene_name, W, H)
-    return {"workload": f"{scene_name} {W}x{H} @{spp}spp depth 50", "value": samples / wall / 1e6, "unit": "Msamples/s",
-            "kernel_ms": st["kernel_ms"], "kernel_Msamples_per_s": samples / (st["kernel_ms"] * 1e-3) / 1e6,
-            "rays_per_sample": st["rays"] / samples, "flop_per_sample": fps, "achieved_tflops": achieved,
-            "frac": achieved / peak, "frac_nonpacked": achieved / (peak / 2), "kernel": abi.VARIANT_NAMES[rv],
-            "shader_mhz": st["shader_mhz"], "active_lane_ratio": pm.get("active_lane_ratio")}
+    rec = {"workload": f"{scene_name} {W}x{H} @{spp}spp depth 50", "value": samples / wall / 1e6, "unit": "Msamples/s",
+           "kernel_ms": st["kernel_ms"], "kernel_Msamples_per_s": samples / (st["kernel_ms"] * 1e-3) / 1e6,
+           "rays_per_sample": st["rays"] / samples, "flop_per_sample": fps, "achieved_tflops": achieved,
+           "frac": achieved / peak, "frac_nonpacked": achieved / (peak / 2),
+           "kernel": f"rt::k_render<{abi.VARIANT_NAMES[rv]}, false>", "shader_mhz": st["shader_mhz"]}
+    if pm.get("active_lane_ratio") is not None:
+        # not measured by this run: a figure of an earlier rocprofv3 --pmc pass, quoted with where it comes from
+        rec["from_profile"] = {"active_lane_ratio": pm["active_lane_ratio"], "profiled_spp": pm.get("profiled_spp"),
+                               "file": "profiles/pmc.json", "source": pm.get("source"), "commit": pm.get("commit")}
+    if st["kernel_ms"] < 2.0:
+        rec["launch_bound"] = (f"{samples} samples are {samples / (256 * 4 * 64 * 4):.1f} per resident lane of a launch that "
+                               "fills the GPU: the figure prices a launch, not the kernel's rate")
+    return rec
 
 
 def cpu_baseline(flat, cam, cfg, seconds=12.0):
@@ -187,8 +195,20 @@ def main():
     # gloo has no reduce() for device tensors; all_reduce gives rank 0 the same sum
     reduce_fn = None if backend == "nccl" else (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
 
+    reduce_events = []  # (start, end) events of each step's reduce on this rank's stream
+
+    def timed_reduce(t):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        if reduce_fn is None:
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        else:
+            reduce_fn(t)
+        e1.record(stream)
+        reduce_events.append((e0, e1))
+
     def step():
-        render_distributed(render_fn, base, rank, world, args.split, reduce_fn)
+        render_distributed(render_fn, base, rank, world, args.split, timed_reduce)
         if rank == 0:
             ctx.tonemap_device(acc.data_ptr(), W * H, spp, argb.data_ptr(), stream.cuda_stream)
 
@@ -204,6 +224,7 @@ def main():
     kernel_ms.clear()
     rays_total.clear()
     shader_mhz_seen.clear()
+    reduce_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -219,6 +240,32 @@ def main():
         elapsed, kern_ms_max, rays = float(tmax[0]), float(tmax[1]), float(tsum[2])
     else:
         kern_ms_max, rays = float(t[1]), float(t[2])
+
+    # Per rank: the path kernel's time and the reduce's, apart (the reduce includes the wait for the slowest rank).
+    # Then one more, untimed, step that checks the exchange: the reduced frame on rank 0 must add up to the sum of
+    # what the ranks rendered (exactly for the tile split, whose shards own disjoint pixels).
+    per_rank = None
+    reduce_check = None
+    if world > 1:
+        my_reduce_ms = sum(a.elapsed_time(b) for a, b in reduce_events) / max(len(reduce_events), 1)
+        gathered = torch.zeros((world, 2), dtype=torch.float64, device=device)  # (all_reduce: the one collective every backend has here)
+        gathered[rank, 0] = float(sum(kernel_ms)) / max(len(kernel_ms), 1)
+        gathered[rank, 1] = my_reduce_ms
+        dist.all_reduce(gathered, op=dist.ReduceOp.SUM)
+        per_rank = [{"rank": r, "kernel_ms": float(gathered[r, 0]), "reduce_ms": float(gathered[r, 1])} for r in range(world)]
+        shard = render_fn(dist_shard_params(base, rank, world, args.split))
+        check = shard.double().sum().reshape(1)
+        dist.all_reduce(check, op=dist.ReduceOp.SUM)
+        if reduce_fn is None:
+            dist.reduce(shard, dst=0, op=dist.ReduceOp.SUM)
+        else:
+            reduce_fn(shard)
+        torch.cuda.synchronize(device)
+        if rank == 0:
+            got, want = float(shard.double().sum()), float(check[0])
+            tol = (1e-9 if args.split == "tile" else 1e-5) * max(abs(want), 1.0)
+            assert abs(got - want) <= tol, f"reduced frame sums to {got!r}, the ranks' shards to {want!r}"
+            reduce_check = {"sum_of_reduced_frame": got, "sum_of_shard_sums": want, "tolerance": tol, "ok": True}
 
     # Roofline numerator: event counts of the SAME kernel from its counting build (a separate,
     # untimed launch at reduced spp; FLOP per sample does not depend on spp beyond MC noise).
@@ -245,6 +292,7 @@ def main():
         traffic = None
         valu_cycles_per_inst = None
         active_lane_ratio = None
+        from_profile = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         # the profiled launch is the headline workload: its counters say nothing about any other
         headline = (args.scene, W, H, spp) == ("cornell-box", 1024, 1024, 1000)
@@ -264,6 +312,11 @@ def main():
                     valu_cycles_per_inst = simd_cycles / prof["valu_wave_insts_per_launch"]
                 if traffic is not None and world > 1:
                     traffic = traffic / world  # measured at N = 1; a rank writes its own tiles' slots only
+                # what this line quotes from that file instead of measuring it: rocprofv3 --pmc cannot run inside bench.py
+                from_profile = {"file": "profiles/traffic.json", "source": prof.get("source"), "commit": prof.get("commit"),
+                                "kernel": prof.get("kernel"),
+                                "fields": ["roofline.traffic", "roofline.active_lane_ratio",
+                                           "roofline.simd_cycles_per_valu_instruction (its instruction count; the cycles are this run's)"]}
             except Exception:
                 traffic = None
         out = {
@@ -286,12 +339,16 @@ def main():
                                       "(device properties); non-packed = half (one v_fma_f32 per lane)",
                          "shader_mhz_measured": shader_mhz, "active_lane_ratio": active_lane_ratio,
                          "traffic": traffic,
-                         "kernel": "rt::k_render<FEAT, false> (the feature-specialised instantiation this scene selects)", "kernel_ms": kern_ms_max,
+                         "kernel": f"rt::k_render<{abi.VARIANT_NAMES[scene.variants()[0]]}, false>", "kernel_ms": kern_ms_max,
+                         "from_profile": from_profile,
                          "simd_cycles_per_valu_instruction": valu_cycles_per_inst,
                          "note": "algorithmic FLOP per event x event counts of the counting build of the same "
                                  "kernel, per GPU, over that GPU's HIP-event kernel time; the path is branchy "
                                  "FP32 VALU work, neither HBM- nor MFMA-bound"},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+            out["reduce_check"] = reduce_check
         if world == 1 and headline and not args.no_other_configs:
             scene.close()   # the other worlds take their own slabs (11 GB for the 4K frame)
             out["other_configs"] = []

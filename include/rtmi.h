@@ -361,15 +361,18 @@ int rt_scene_create_from_file(rt_ctx* ctx, const char* path, rt_scene** out);
  * reference's fan-out of a frame over one thread per image row and its latch (core.clj:44-48,
  * 95,109-128). rt_multi_init binds one context per listed device; rt_multi_scene_create uploads
  * the world to each of them; rt_multi_render runs one host thread per device, each rendering its
- * shard through rt_render_device (RT_SPLIT_TILES: device i of n owns the 8x8 tiles t with
- * t % n == i, all samples, and the frame is bit-identical to a single-GPU render;
+ * shard through rt_render_device (RT_SPLIT_TILES: device i of n owns the 8x8 tiles that rt_params'
+ * shard_index = i, shard_count = n name - one of every n consecutive tiles, the place moving on by
+ * one per tile row - all samples, and the frame is bit-identical to a single-GPU render;
  * RT_SPLIT_SAMPLES: device i renders samples [spp*i/n, spp*(i+1)/n) of every pixel, and the FP32
  * sums differ from a single-GPU render by re-association only), then ONE RCCL reduce(sum) of the
  * width*height*3 FP32 accumulators onto the first device (over xGMI), the pixel post-process there,
  * and the copy to the caller's host buffers (same meaning as rt_render's). params->shard_index /
  * shard_count must be 0. RCCL (librccl.so) is loaded on first need: never for one device, and a
  * list that names ONE device several times (the fan-out rehearsed on a one-GPU machine) is summed
- * by a kernel on that device in list order. Errors of these calls are reported by
+ * by a kernel on that device in list order. (The reduce between distinct devices is exercised by
+ * tests/test_gpu_multi.py wherever two or more GPUs are visible; a one-GPU machine can only run
+ * the repeated-device form and a one-rank RCCL self-test.) Errors of these calls are reported by
  * rt_multi_last_error().
  */
 typedef struct rt_multi rt_multi;

@@ -854,7 +854,7 @@ hipError_t launch_tonemap(const float* rgb_sum, int n_pixels, int spp, uint32_t*
   return hipGetLastError();
 }
 
-// Does instantiation `variant` (0 V_RECT .. 6 V_FULL) support everything the scene needs?
+// Does instantiation `variant` (0 V_RECT .. 7 V_BALLS, the order of `masks` below) support everything the scene needs?
 bool variant_covers(const DScene& S, int variant) {
   const bool small = S.n_prims <= RT_LDS_PRIMS && S.n_chains <= RT_LDS_CHAINS;
   const uint32_t masks[RT_N_VARIANTS] = {V_RECT, V_SMOKE, V_LIST, V_SPH, V_NOISE, V_ALL_DEEP, V_FULL, V_BALLS};

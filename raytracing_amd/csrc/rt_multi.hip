@@ -18,9 +18,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <set>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -39,7 +41,13 @@ struct Rccl {
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   std::string why;
+  // One handle for the process, opened on first need and kept: RCCL registers its device code with the HIP runtime
+  // when it is loaded, and unloading it under a live runtime is not something every ROCm release survives, so it is
+  // never closed; every rt_multi handle and the selftest share it, so repeated use opens nothing more.
+  static Rccl& shared() { static Rccl r; return r; }
+  static std::mutex& lock() { static std::mutex m; return m; }
   bool load() {
+    std::lock_guard<std::mutex> guard(lock());
     if (so) return true;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
       so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
@@ -86,7 +94,6 @@ struct rt_multi {
   uint32_t* d_argb = nullptr;     // on the first device
   size_t argb_bytes = 0;
   bool distinct = true;           // no device named twice
-  Rccl rccl;
   std::vector<nccl_comm> comm;
 };
 struct rt_multi_scene {
@@ -103,7 +110,7 @@ void rt_multi_shutdown(rt_multi* m) {
   for (size_t i = 0; i < m->ctx.size(); ++i) {
     if (!m->ctx[i]) continue;  // (never bound: its device id may not even exist)
     hipSetDevice(m->devices[i]);
-    if (i < m->comm.size() && m->comm[i]) m->rccl.CommDestroy(m->comm[i]);
+    if (i < m->comm.size() && m->comm[i]) Rccl::shared().CommDestroy(m->comm[i]);
     if (i < m->d_sum.size() && m->d_sum[i]) hipFree(m->d_sum[i]);
     if (i < m->stream.size() && m->stream[i]) hipStreamDestroy(m->stream[i]);
     if (m->ctx[i]) rt_shutdown(m->ctx[i]);
@@ -136,11 +143,11 @@ int rt_multi_init(const int32_t* device_ids, int32_t n_devices, rt_multi** out) 
       }
     }
     if (n_devices > 1 && m->distinct) {
-      if (!m->rccl.load()) { std::string why = m->rccl.why; rt_multi_shutdown(m); return mfail(RT_ERR_HIP, "%s", why.c_str()); }
+      if (!Rccl::shared().load()) { std::string why = Rccl::shared().why; rt_multi_shutdown(m); return mfail(RT_ERR_HIP, "%s", why.c_str()); }
       m->comm.assign((size_t)n_devices, nullptr);
-      int e = m->rccl.CommInitAll(m->comm.data(), n_devices, m->devices.data());
+      int e = Rccl::shared().CommInitAll(m->comm.data(), n_devices, m->devices.data());
       if (e != 0) {
-        std::string why = m->rccl.GetErrorString(e);
+        std::string why = Rccl::shared().GetErrorString(e);
         m->comm.clear();
         rt_multi_shutdown(m);
         return mfail(RT_ERR_HIP, "ncclCommInitAll failed: %s", why.c_str());
@@ -159,7 +166,7 @@ int rt_multi_init(const int32_t* device_ids, int32_t n_devices, rt_multi** out) 
 // ncclReduce(float, sum, root 0), ncclCommDestroy) on ONE device: a reduce over one rank must
 // return its input. What a one-GPU machine can check of the collective path.
 int rt_multi_selftest_rccl(int32_t device_id) {
-  Rccl R;
+  Rccl& R = Rccl::shared();
   if (!R.load()) return mfail(RT_ERR_HIP, "%s", R.why.c_str());
   if (hipSetDevice(device_id) != hipSuccess) return mfail(RT_ERR_HIP, "hipSetDevice(%d) failed", device_id);
   nccl_comm comm = nullptr;
@@ -275,21 +282,32 @@ int rt_multi_render(rt_multi* m, const rt_multi_scene* s, const rt_camera* cam, 
       // (contexts that share a device share nothing else, but their renders run one after the other)
       for (int i = 0; i < n; ++i) work(i);
     } else {
+      // one host thread per device; a thread that cannot be started (std::system_error) must not unwind past the
+      // ones already running: they are joined first, and the device does its share on this thread instead
       std::vector<std::thread> threads;
-      for (int i = 0; i < n; ++i) threads.emplace_back(work, i);
+      threads.reserve((size_t)n);
+      std::vector<int> inline_work;
+      for (int i = 0; i < n; ++i) {
+        try {
+          threads.emplace_back(work, i);
+        } catch (const std::system_error&) {
+          inline_work.push_back(i);
+        }
+      }
+      for (int i : inline_work) work(i);
       for (auto& t : threads) t.join();
     }
     for (int i = 0; i < n; ++i)
       if (rc[(size_t)i]) return mfail(rc[(size_t)i], "device %d: %s", m->devices[(size_t)i], why[(size_t)i].c_str());
     // ---- combine the accumulators on the first device
     if (n > 1 && m->distinct) {
-      int e = m->rccl.GroupStart();
+      int e = Rccl::shared().GroupStart();
       for (int i = 0; i < n && e == 0; ++i) {
         hipSetDevice(m->devices[(size_t)i]);
-        e = m->rccl.Reduce(m->d_sum[(size_t)i], m->d_sum[(size_t)i], npix * 3, kNcclFloat, kNcclSum, 0, m->comm[(size_t)i], m->stream[(size_t)i]);
+        e = Rccl::shared().Reduce(m->d_sum[(size_t)i], m->d_sum[(size_t)i], npix * 3, kNcclFloat, kNcclSum, 0, m->comm[(size_t)i], m->stream[(size_t)i]);
       }
-      const int e2 = m->rccl.GroupEnd();
-      if (e != 0 || e2 != 0) return mfail(RT_ERR_HIP, "ncclReduce failed: %s", m->rccl.GetErrorString(e ? e : e2));
+      const int e2 = Rccl::shared().GroupEnd();
+      if (e != 0 || e2 != 0) return mfail(RT_ERR_HIP, "ncclReduce failed: %s", Rccl::shared().GetErrorString(e ? e : e2));
       for (int i = 0; i < n; ++i) {
         hipSetDevice(m->devices[(size_t)i]);
         if (hipStreamSynchronize(m->stream[(size_t)i]) != hipSuccess) return mfail(RT_ERR_HIP, "device %d failed during the reduce", m->devices[(size_t)i]);

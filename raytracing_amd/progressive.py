@@ -65,16 +65,24 @@ def load_checkpoint(path: str, base: abi.rt_params, digest: str = ""):
 
 def render_progressive(render_fn: Callable[[abi.rt_params], np.ndarray], base: abi.rt_params, slice_spp: int,
                        checkpoint: Optional[str] = None,
-                       on_slice: Optional[Callable[[np.ndarray, int], None]] = None, digest: str = ""):
+                       on_slice: Optional[Callable[[np.ndarray, int], None]] = None, digest: str = "",
+                       flat=None, cam: Optional[abi.rt_camera] = None):
     """Renders `base` in slices of `slice_spp` samples. render_fn(params) -> H x W x 3 FP32 sums of
     that slice. Resumes from `checkpoint` when it exists and matches the job; writes it after every
-    slice. on_slice(rgb_sum, samples_done) is called after every slice (preview hook). `digest`
-    (job_digest) ties the checkpoint to the world, camera, background and slice size.
+    slice. on_slice(rgb_sum, samples_done) is called after every slice (preview hook). A checkpoint
+    is tied to the world, camera, background and slice size by a digest: pass the flattened world
+    and the camera (`flat`, `cam`) and it is job_digest of them, or pass `digest` yourself. An
+    existing checkpoint is never continued without one: its sums could be another world's.
     Returns (rgb_sum, samples_done)."""
     if slice_spp <= 0:
         raise ValueError("slice_spp must be positive")
+    if not digest and flat is not None and cam is not None:
+        digest = job_digest(flat, cam, base, slice_spp)
     acc, done = None, 0
     if checkpoint and os.path.exists(checkpoint):
+        if not digest:
+            raise ValueError(f"checkpoint {checkpoint} exists: continuing it needs flat= and cam= (or digest=), "
+                             "so that it can be checked against this world, camera and slice size")
         acc, done = load_checkpoint(checkpoint, base, digest)
     while done < base.spp:
         n = min(slice_spp, base.spp - done)

@@ -1,9 +1,10 @@
 """rt_multi_*: several GPUs behind one handle for a single-process caller (the stand-in for the
 reference's thread-per-row fan-out and latch, core.clj:109-128).
 
-The GPU box has ONE device, so what runs here is the one-device path and the fan-out rehearsed with
-one device named several times (shards, ordering, the sum on the first device, the post-process).
-The RCCL reduce between DISTINCT devices cannot run on this box and is untested."""
+A box with ONE device runs the one-device path and the fan-out rehearsed with one device named several
+times (shards, ordering, the sum on the first device, the post-process). The RCCL reduce between
+DISTINCT devices runs in test_distinct_devices_reduce_over_rccl wherever two or more devices are visible
+and is skipped, saying so, where there is one."""
 import numpy as np
 import pytest
 
@@ -59,6 +60,45 @@ def test_fan_out_over_a_repeated_device(gpu_ctx, name, n):
     assert s4["samples"] == W * H * 2
     ms.close()
     m.close()
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("name", ["cornell-box", "final-scene"])
+def test_distinct_devices_reduce_over_rccl(gpu_ctx, name):
+    """rt_multi_render over distinct device ids: one host thread per device, the frames summed onto the first
+    device by one grouped ncclReduce (core.clj:109-128 fans rows out to threads and waits on a latch). The tile
+    split must give the single-GPU frame bit for bit (disjoint pixels, zeros elsewhere), the sample split the
+    same samples with the FP32 sums re-associated."""
+    n = _n_devices()
+    if n < 2:
+        pytest.skip(f"{n} GPU visible: the reduce between distinct devices needs two or more "
+                    "(the repeated-device tests above cover everything but RCCL itself)")
+    ids = list(range(min(n, 8)))
+    cfg, flat, cam = scene_bundle(name)
+    W, H, spp = 131, 77, 2 * len(ids) + 1
+    p = abi.make_params(W, H, spp, 50, cfg["background"], seed=77)
+    sc = gpu_ctx.scene(flat)
+    rgb, argb, st = sc.render(cam, p)
+    sc.close()
+    for use in ([0, 1], ids):
+        m = lib.MultiContext(use)
+        assert m.device_count() == len(use)
+        ms = m.scene(flat)
+        r2, a2, s2 = ms.render(cam, p, abi.RT_SPLIT_TILES)
+        assert np.array_equal(r2, rgb) and np.array_equal(a2, argb)
+        assert s2["rays"] == st["rays"] and s2["samples"] == W * H * spp
+        r3, a3, s3 = ms.render(cam, p, abi.RT_SPLIT_SAMPLES)
+        np.testing.assert_allclose(r3, rgb, rtol=1e-5, atol=1e-5)
+        assert s3["rays"] == st["rays"] and s3["samples"] == W * H * spp
+        # twice through the same communicator: the second reduce must not see the first one's frame
+        r4, a4, _ = ms.render(cam, p, abi.RT_SPLIT_TILES)
+        assert np.array_equal(r4, rgb) and np.array_equal(a4, argb)
+        ms.close()
+        m.close()
 
 
 def test_multi_errors(gpu_ctx):

@@ -43,7 +43,7 @@ def test_progressive_on_the_gpu(gpu_ctx, name, tmp_path):
         render_progressive(interrupted, base, SL, checkpoint=ck, digest=dg)
     part, d = load_checkpoint(ck, base, dg)
     assert d == 12
-    resumed, done = render_progressive(render_fn, base, SL, checkpoint=ck, digest=dg)
+    resumed, done = render_progressive(render_fn, base, SL, checkpoint=ck, flat=flat, cam=cam)   # the digest formed inside
     assert done == SPP
     np.testing.assert_array_equal(resumed, acc)
     # the checkpoint of this job is refused for another world, another camera, another slice size

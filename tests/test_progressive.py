@@ -50,10 +50,14 @@ def test_resume_from_checkpoint_is_exact(job, tmp_path):
         calls.append((p.sample_offset, p.spp))
         return render_fn(p)
     with pytest.raises(KeyboardInterrupt):
-        render_progressive(interrupted, base, 4, checkpoint=ck)
-    _, done = load_checkpoint(ck, base)
+        render_progressive(interrupted, base, 4, checkpoint=ck, digest="job-a")
+    _, done = load_checkpoint(ck, base, "job-a")
     assert done == 8 and calls == [(0, 4), (4, 4)]
-    resumed, done = render_progressive(render_fn, base, 4, checkpoint=ck)
+    with pytest.raises(ValueError):   # an existing checkpoint is not continued blind
+        render_progressive(render_fn, base, 4, checkpoint=ck)
+    with pytest.raises(ValueError):   # nor for a job that calls itself something else
+        render_progressive(render_fn, base, 4, checkpoint=ck, digest="job-b")
+    resumed, done = render_progressive(render_fn, base, 4, checkpoint=ck, digest="job-a")
     assert done == SPP
     np.testing.assert_array_equal(resumed, straight)
 

@@ -47,10 +47,16 @@ def test_noalloc_matches_render_device(gpu_ctx):
     (a_rgb, a_argb), (b_rgb, b_argb) = _both(sc, cam, small)
     assert np.array_equal(a_rgb.view(np.uint32), b_rgb.view(np.uint32)) and np.array_equal(a_argb, b_argb)
     assert a_rgb.max() > 0 and (a_rgb == 0).any()     # the other shard's pixels are written as 0
-    # only one output asked for
+    # only one output asked for; and what the entry point is for: the device's free memory is the same before and
+    # after a run of calls (hipMemGetInfo: an allocation by the library, however it were made, would show)
     rgb = torch.zeros((19, 37, 3), dtype=torch.float32, device="cuda:0")
-    sc.render_device_noalloc(cam, small, rgb.data_ptr(), 0)
     torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    for _ in range(4):
+        sc.render_device_noalloc(cam, small, rgb.data_ptr(), 0)
+    free_after, _ = torch.cuda.mem_get_info()
+    torch.cuda.synchronize()
+    assert free_after == free_before, f"free device memory moved by {free_before - free_after} bytes across noalloc calls"
     assert np.array_equal(rgb.cpu().numpy().view(np.uint32), a_rgb.view(np.uint32))
     # beyond the array: refused with a message that says why, nothing launched
     with pytest.raises(RtError) as e:

@@ -45,5 +45,10 @@ if os.path.exists(headline):
     if m:
         rec["simd_cycles_per_valu_instruction"] = float(m.group(1))
     out["cornell-box 1024x1024"] = rec
+import subprocess
+commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                        cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
+for rec in out.values():
+    rec["commit"] = commit   # the tree the profiled library was built from
 json.dump(out, open(os.path.join(root, "pmc.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -3,6 +3,7 @@ bench.py quotes) from a tools/profile.sh summary. Usage: python tools/make_traff
 import json
 import os
 import re
+import subprocess
 import sys
 
 src = sys.argv[1]
@@ -38,5 +39,8 @@ out = {
     "active_lane_ratio": round(per["SQ_THREAD_CYCLES_VALU"] / (per["SQ_ACTIVE_INST_VALU"] * 64), 4),
 }
 dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json")
+# the tree the profiled library was built from (bench.py quotes it beside every figure it takes from this file)
+out["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                               cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
