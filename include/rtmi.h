@@ -357,6 +357,22 @@ int rt_scene_create_from_memory(rt_ctx* ctx, const void* bytes, uint64_t n_bytes
 int rt_scene_create_from_file(rt_ctx* ctx, const char* path, rt_scene** out);
 
 /*
+ * (image-texture url), texture.clj:68-81: the reference reads its texture files with
+ * javax.imageio.ImageIO/read and keeps rows of [R G B] bytes (texture.clj:74-80). This call decodes
+ * a JPEG file held in memory (resources/earthmap.jpg and the two files beside it are JPEGs, whatever
+ * map2.png is called) to that layout: height * width * 3 bytes, top row first, R G B - what
+ * rt_scene_desc.img_rgb8 takes. Huffman-coded 8-bit JPEG, sequential or progressive, one or three
+ * components, any integral sampling factors, restart intervals; reconstruction as the IJG decoder
+ * behind ImageIO does it by default (accurate integer inverse DCT, triangle-filter chroma upsampling,
+ * 16-bit fixed-point YCbCr -> RGB), so the texels are that decoder's. Host code: no context and no
+ * GPU needed. rgb8 = NULL only reports the size. RT_ERR_ARG: not a JPEG file, a damaged one, or
+ * capacity < width * height * 3; RT_ERR_UNSUPPORTED: arithmetic coding, lossless / hierarchical
+ * processes, 12-bit samples, four components.
+ */
+int rt_image_decode_jpeg(const uint8_t* bytes, uint64_t n_bytes, int32_t* width, int32_t* height,
+                         uint8_t* rgb8, uint64_t capacity);
+
+/*
  * Several GPUs behind one handle, for a caller that is ONE process (the JVM): what replaces the
  * reference's fan-out of a frame over one thread per image row and its latch (core.clj:44-48,
  * 95,109-128). rt_multi_init binds one context per listed device; rt_multi_scene_create uploads

@@ -39,6 +39,16 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+}  // namespace
+namespace rt {
+// for the library's other translation units: sets what rt_last_error() returns on this thread
+int set_error(int code, const char* message) {
+  g_err = message;
+  return code;
+}
+}  // namespace rt
+namespace {
+
 // Runs f(); a C++ exception never leaves the library.
 template <class F>
 int guarded(const char* what, F&& f) {

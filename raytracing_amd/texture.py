@@ -85,15 +85,18 @@ ASSET_DIR = os.path.join(os.path.dirname(__file__), "assets")
 
 
 def load_rgb8(path: str) -> np.ndarray:
-    """Decode an image file to (h, w, 3) uint8. `.npz` assets (key 'rgb8') are decoded with numpy
-    alone; anything else goes through Pillow. The reference decodes with javax.imageio
-    (texture.clj:72); JPEG decoders may differ by one LSB per texel."""
+    """Decode an image file to (h, w, 3) uint8, as ImageIO/read does for the reference (texture.clj:72).
+    JPEG files (by their first bytes, whatever the name: resources/map2.png is one) are decoded by the
+    library's own decoder, rt_image_decode_jpeg; `.npz` files (key 'rgb8') hold decoded arrays."""
     if path.endswith(".npz"):
         with np.load(path) as z:
             return np.ascontiguousarray(z["rgb8"], dtype=np.uint8)
-    from PIL import Image
-    with Image.open(path) as im:
-        return np.ascontiguousarray(np.asarray(im.convert("RGB")), dtype=np.uint8)
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:2] != b"\xff\xd8":
+        raise ValueError(f"{path}: only JPEG files (and .npz arrays) are read")
+    from . import lib
+    return lib.decode_jpeg(data)
 
 
 def image_texture(source=None) -> ImageTexture:  # texture.clj:68-81
@@ -106,6 +109,5 @@ def image_texture(source=None) -> ImageTexture:  # texture.clj:68-81
 
 
 def resource(name: str) -> str:
-    """Stand-in for (io/resource name): the decoded copy shipped with this package."""
-    stem = os.path.splitext(name)[0]
-    return os.path.join(ASSET_DIR, stem + "_rgb8.npz")
+    """Stand-in for (io/resource name): the file of that name shipped with this package."""
+    return os.path.join(ASSET_DIR, name)
