@@ -1235,7 +1235,9 @@ RT_DEV float perlin_noise(const X& ctx, int pid, D3 p, T& tally) {
   float u = hermite((float)(p.x - fx)), v = hermite((float)(p.y - fy)), w = hermite((float)(p.z - fz));
   int i = (int)(long long)fx, j = (int)(long long)fy, k = (int)(long long)fz;
   const uint8_t* perm = ctx.lds_perlin_perm + pid * 768;
-  const float4* vec = reinterpret_cast<const float4*>(ctx.lds_perlin_vec) + pid * 256;
+  // (a gradient is three floats at a 16-byte stride: three registers per corner in flight, not four)
+  struct G3 { float x, y, z, pad; };
+  const G3* vec = reinterpret_cast<const G3*>(ctx.lds_perlin_vec) + pid * 256;
   float uu = hermite(u), vv = hermite(v), ww = hermite(w);
   float acc = 0.f;
 #pragma unroll
@@ -1250,8 +1252,9 @@ RT_DEV float perlin_noise(const X& ctx, int pid, D3 p, T& tally) {
       for (int dk = 0; dk < 2; ++dk) {
         int pz = perm[512 + ((k + dk) & 255)];
         float bw = dk ? ww : 1.0f - ww;
-        float4 c = vec[px | py | pz];
-        float dp = fmaf(c.x, u - di, fmaf(c.y, v - dj, c.z * (w - dk)));
+        const G3* g = vec + (px | py | pz);
+        const float cx = g->x, cy = g->y, cz = g->z;
+        float dp = fmaf(cx, u - di, fmaf(cy, v - dj, cz * (w - dk)));
         acc = fmaf((bu * bv) * bw, dp, acc);
       }
     }

@@ -27,6 +27,12 @@ TOL = 1e-5
 # grazes an edge, an exact tie): set from what is observed on the MI355X (profiles/r02_parity_stats.txt).
 # Observed: 0 of 20 000 probe rays in every world; path rays 4 of 9 249 (Cornell box, rays leaving
 # the rotated blocks along their faces), 0 elsewhere; scattered rays at most 3 of 12 301.
+# Largest error of a hit's distance t |d| among the records that agree, in ulps (2^-24) of the largest coordinate of
+# the ray's origin and the hit point. It is the error of the origin's offset from the surface (an ulp or two of the
+# coordinate after the FP32 chain motion) divided by the cosine of incidence, so grazing rays carry the largest.
+# Observed on the MI355X (profiles/r03_parity_stats.txt): at most 47 over every world of the suite (two media
+# worlds of the fuzz set), 44 on the Cornell box's path rays (99.99th percentile 17), 19 on its probe rays.
+DIST_ULPS = 128.0
 KNIFE_PROBE = 5e-5
 KNIFE_PATH = 6e-4
 
@@ -51,10 +57,20 @@ def _check_hits(dev, orc, o32, d32, knife_budget, uv_exempt=(), label=None):
     bad = both & ((t_err > TOL) | (e["p"] > TOL) | (e["n"] > TOL) | (e["uv"] > TOL) | e["front"] | e["mat"])
     n_bad = int(bad.sum()) + e["hit_mismatch"]
     good = both & ~bad
+    # What the floor above stands for, as an absolute bound: the FP32 path carries ray origins (in chain space too:
+    # translate.clj:11, rotate.clj:18-22) to half an ulp of their size, so the DISTANCE to the hit, t |d|, is off
+    # by a few ulps of the largest coordinate involved however short the distance is. For a hit an inch from a
+    # ray's origin 800 units from the world's, that is a large error relative to t and none relative to the world.
+    dist_err = np.abs(dev["t"].astype(np.float64) - orc[:, 0]) * np.linalg.norm(d32.astype(np.float64), axis=1)
+    size = np.maximum(np.maximum(np.abs(o32).max(axis=1), np.abs(orc[:, 1:4]).max(axis=1)), 1.0)
+    dist_ulps = dist_err / (size * 2.0 ** -24)
+    assert not good.any() or dist_ulps[good].max() <= DIST_ULPS, (
+        f"a hit's distance is off by {dist_ulps[good].max():.1f} ulps of its largest coordinate (bound {DIST_ULPS})")
     if label and good.any():
         q = lambda a: float(np.quantile(a[good], 0.9999))
         print(f"[parity] {label}: {n} rays, {int(both.sum())} hits; knife-edge {n_bad} (hit/miss {e['hit_mismatch']}); "
               f"t relative to |t| alone: 99.99th pct {q(e['t']):.2e} max {e['t'][good].max():.2e}; "
+              f"distance error in ulps of the largest coordinate: 99.99th pct {q(dist_ulps):.2f} max {dist_ulps[good].max():.2f}; "
               f"99.99th pct t {q(t_err):.2e} p {q(e['p']):.2e} n {q(e['n']):.2e} uv {q(e['uv']):.2e}; "
               f"max t {t_err[good].max():.2e} p {e['p'][good].max():.2e} n {e['n'][good].max():.2e} uv {e['uv'][good].max():.2e}")
     if n_bad > max(1, int(knife_budget * n)):
