@@ -1044,6 +1044,8 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
   }
 
   std::vector<DChainRec> chain_recs;
+  struct ChainD { double A, B, t[3], A1, B1, s0, c0, s01, c01; };  // the same in FP64, for the per-rect constants of DPrimInfo
+  std::vector<ChainD> chain_d;
   for (auto& c : F.chains) {
     // the record side, composed in FP64 from the innermost wrapper outwards (see DChainRec)
     DChainRec rec;
@@ -1052,6 +1054,7 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
     rec.inner = c.size() >= 2 ? 1 : 0;
     double A = 1.0, B = 0.0, t[3] = {0.0, 0.0, 0.0};
     rec.A1 = 1.f; rec.B1 = 0.f;
+    double A1d = 1.0, B1d = 0.0;
     for (size_t i = c.size(); i-- > 0;) {
       if (c[i].kind == DOP_TRANSLATE) {
         t[0] += c[i].da; t[1] += c[i].db; t[2] += c[i].dc;
@@ -1062,7 +1065,7 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
         A = nA; B = nB; t[0] = nx; t[2] = nz;
         ++rec.n_rotate;
       }
-      if (i == 1) { rec.A1 = (float)A; rec.B1 = (float)B; }  // everything but the outermost
+      if (i == 1) { rec.A1 = (float)A; rec.B1 = (float)B; A1d = A; B1d = B; }  // everything but the outermost
     }
     rec.A = (float)A; rec.B = (float)B; rec.tx = (float)t[0]; rec.ty = (float)t[1]; rec.tz = (float)t[2];
     // the ray side's turn (rotate.clj:14-24, angles add) after the outermost and after the two outermost
@@ -1075,6 +1078,7 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
     }
     rec.s0 = (float)s0; rec.c0 = (float)c0; rec.s01 = (float)s01; rec.c01 = (float)c01;
     chain_recs.push_back(rec);
+    chain_d.push_back(ChainD{A, B, {t[0], t[1], t[2]}, A1d, B1d, s0, c0, s01, c01});
   }
 
   std::vector<DMat> mats((size_t)d->n_mats);
@@ -1152,6 +1156,21 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
       I.oz = (P.type & 15) == RT_PRIM_XY_RECT ? 1.f : 0.f;
     }
     I.rc = G.rc; I.rs = G.rs; I.bx = G.bx; I.by = G.by; I.bz = G.bz;
+    if ((P.type & 15) >= RT_PRIM_XY_RECT && (P.type & 15) <= RT_PRIM_YZ_RECT && G.chain > 0) {
+      const ChainD& C = chain_d[(size_t)G.chain];
+      const double o[3] = {I.ox, I.oy, I.oz};
+      // the normal inside the outermost wrapper, then outside it (rotate.clj:37-42 composed: x' = A x + B z, z' = B x + A z)
+      const double n1[3] = {C.A1 * o[0] + C.B1 * o[2], o[1], C.B1 * o[0] + C.A1 * o[2]};
+      const double nn[3] = {C.c0 * n1[0] + C.s0 * n1[2], n1[1], C.s0 * n1[0] + C.c0 * n1[2]};
+      // dot(turn(d), n) = dot(d, turn^T(n)), turn(d) = (c dx - s dz, dy, s dx + c dz) (rotate.clj:19-27)
+      const double g1[3] = {C.c01 * n1[0] + C.s01 * n1[2], n1[1], -C.s01 * n1[0] + C.c01 * n1[2]};
+      const double g0[3] = {C.c0 * nn[0] + C.s0 * nn[2], nn[1], -C.s0 * nn[0] + C.c0 * nn[2]};
+      I.fA = (float)C.A; I.fB = (float)C.B; I.ftx = (float)C.t[0]; I.fty = (float)C.t[1]; I.ftz = (float)C.t[2];
+      I.fnx = (float)nn[0]; I.fny = (float)nn[1]; I.fnz = (float)nn[2];
+      I.g0x = (float)g0[0]; I.g0y = (float)g0[1]; I.g0z = (float)g0[2];
+      I.g1x = (float)g1[0]; I.g1y = (float)g1[1]; I.g1z = (float)g1[2];
+      I.finner = chain_recs[(size_t)G.chain].inner;
+    }
     I.mtype = M.type; I.mflags = M.flags; I.mtex = M.tex; I.r = M.r; I.g = M.g; I.b = M.b; I.x = M.x;
     infos[i] = I;
   }

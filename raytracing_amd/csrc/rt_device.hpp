@@ -1020,6 +1020,25 @@ RT_DEV void chain_unwind_rec(CHAIN C, V3 world_d, Rec& rec, T& tally) {
   rec.n = rec.front ? nn : neg(nn);
 }
 
+// The same for a rect, from the constants its DPrimInfo carries (see there): on entry rec.front says how the rect's own
+// face test oriented its axis normal (rectangles.clj:37), and every wrapper can only flip the mapped normal.
+template <class INFO, class T>
+RT_DEV void rect_unwind(INFO F, V3 world_d, Rec& rec, T& tally) {
+  const V3 p = rec.p;
+  rec.p = mk(fmaf(F->fA, p.x, fmaf(F->fB, p.z, F->ftx)), p.y + F->fty, fmaf(F->fB, p.x, fmaf(F->fA, p.z, F->ftz)));
+  const V3 nn = mk(F->fnx, F->fny, F->fnz);
+  const float q0 = dot(world_d, mk(F->g0x, F->g0y, F->g0z));
+  const float q1 = dot(world_d, mk(F->g1x, F->g1y, F->g1z));
+  const bool sm = rec.front;  // the sign the innermost test gave the normal (true: as stored)
+  // the second-outermost wrapper keeps what it is handed when that faces its ray, else flips it (rotate.clj:43,
+  // translate.clj:13); a single wrapper has no such inner test
+  const bool keep = F->finner == 0 || (sm ? q1 < 0.0f : q1 > 0.0f);
+  const bool s1 = keep ? sm : !sm;
+  const bool front = s1 ? q0 < 0.0f : q0 > 0.0f;
+  rec.front = front;
+  rec.n = (front == s1) ? nn : neg(nn);
+}
+
 template <class X, class T>
 RT_DEV void chain_unwind(const X& ctx, int chain, V3 world_d, Rec& rec, T& tally) {
   if constexpr (X::has(F_CHAINS)) {
@@ -1164,7 +1183,22 @@ RT_DEV void hit_record(const X& ctx, const Ray& wr, const Best& best, bool want_
     if constexpr (X::has(F_IMAGE)) want_uv = want_uv || (I.mflags & DMAT_NEEDS_UV) != 0;
     prim_record<X>(S, prim, I, rx, best.t, best.root, want_uv, rec, tally);
     RT_MARK(unwind);
-    chain_unwind(ctx, I.chain, wr.d, rec, tally);
+    if constexpr (X::has(F_CHAINS) && X::rects()) {
+      // a rect below a chain takes its record back up from constants of its own (one lookup, no chain record)
+      if ((!X::has(F_SPHERES) || is_rect(prim_type(I.type_group))) && I.chain != 0) {
+        if constexpr (T::on) {
+          const int n_ops = cptr(S.chain_recs)[I.chain].n_ops, n_rot = cptr(S.chain_recs)[I.chain].n_rotate;
+          tally.template add<RT_EV_ROTATE_REC>((uint32_t)n_rot);
+          tally.template add<RT_EV_TRANSLATE_REC>((uint32_t)(n_ops - n_rot));
+        }
+        if constexpr (X::has(F_SMALL)) rect_unwind(ctx.lds_info + prim, wr.d, rec, tally);
+        else rect_unwind(cptr(S.prim_info) + prim, wr.d, rec, tally);
+      } else {
+        chain_unwind(ctx, I.chain, wr.d, rec, tally);
+      }
+    } else {
+      chain_unwind(ctx, I.chain, wr.d, rec, tally);
+    }
   } else {
     if constexpr (X::has(F_MEDIA)) {
       // constant_medium.clj:38-44: p = ray-at r t, normal [1 0 0], front-face true, no u/v

@@ -142,7 +142,7 @@ struct DGroup64 {  // the same motion in FP64, for DGROUP_SPHERES_UNDER_CHAIN gr
 #define DGROUP_SPHERES_UNDER_CHAIN 1  // spheres below a non-identity chain: the ray is carried into
                                       // chain space in FP64 (as a float hi + lo pair)
 
-// 96 bytes: everything the winner of a traversal needs for its record and its scatter, gathered
+// 160 bytes: everything the winner of a traversal needs for its record and its scatter, gathered
 // so that the divergent (per-lane) lookup after the loops is ONE memory round trip. Staged in
 // LDS for small scenes.
 struct DPrimInfo {
@@ -155,6 +155,19 @@ struct DPrimInfo {
   float r, g, b;                           // DMat.r g b
   float x;                                 // DMat.x
   float ox, oy, oz;                        // rects: the unit vector of the constant axis (outward normal)
+  // Rects below a chain: the chain's record side (DChainRec) applied to THIS rect, whose normal is an axis. The
+  // point map (fA fB ftx fty ftz = the chain's A B tx ty tz); the normal every wrapper can only flip, carried through
+  // all of them (fn) and through all but the outermost (its image under the ray turns: g1); the outermost's face
+  // test as a dot product with the WORLD direction (g0 = the transpose of the outermost ray turn applied to fn,
+  // g1 = that of the two outermost turns applied to the inner normal). Formed in FP64 on the host and rounded once:
+  // two dot products and a sign replace two maps, two ray turns and two dot products per record (rotate.clj:31-47,
+  // translate.clj:13-17), and the record needs no second lookup by chain.
+  float fA, fB, ftx, fty;
+  float ftz, fnx, fny, fnz;
+  float g0x, g0y, g0z, g1x;
+  float g1y, g1z;
+  int32_t finner;                          // DChainRec.inner
+  int32_t fpad;
 };
 #define RT_LDS_PRIMS 256  // scenes up to this many flattened primitives keep DPrimInfo in LDS
 
