@@ -164,8 +164,8 @@ struct Rng {
   }
   // The k-th element of (repeatedly #(random-vec3 -1 1)) at invocation `bounce`. Keyed stream:
   // draw 0 is never tested by the reference's reduce, so it is not addressed; draw k >= 1 is
-  // candidate j = k - 1, two candidates per Philox block (block j >> 1, half j & 1), three 21-bit
-  // uniforms each: x, y = top 21 bits of the half's two words, z = the 11 + 10 bits below them.
+  // candidate j = k - 1, two candidates per Philox block (block j >> 1, half j & 1), three 16-bit
+  // uniforms each: x, y = the upper and the lower half of the pair's first word, z = the upper half of its second.
   V3 sphere_trial(int bounce, int k) {
     double ux, uy, uz;
     if (scripted()) {
@@ -177,10 +177,10 @@ struct Rng {
       int j = k - 1;
       block(P_SPHERE, bounce, (uint32_t)(j >> 1), o);
       uint32_t wa = o[(j & 1) * 2], wb = o[(j & 1) * 2 + 1];
-      const double S = 1.0 / 2097152.0;  // 2^-21
-      ux = (double)(wa >> 11) * S;
-      uy = (double)(wb >> 11) * S;
-      uz = (double)(((wa & 0x7FFu) << 10) | ((wb >> 1) & 0x3FFu)) * S;
+      const double S = 1.0 / 65536.0;  // 2^-16; the uniform is the centre of its cell, (k + 1/2) / 2^16
+      ux = ((double)(wa >> 16) + 0.5) * S;
+      uy = ((double)(wa & 0xFFFFu) + 0.5) * S;
+      uz = ((double)(wb >> 16) + 0.5) * S;
     }
     return {-1.0 + 2.0 * ux, -1.0 + 2.0 * uy, -1.0 + 2.0 * uz};
   }

@@ -106,7 +106,7 @@ struct Tally<true> {
 // so its value does not depend on evaluation order or on which GPU runs the sample. The key is the same
 // for every lane: its schedule (two additions per round) runs on the scalar unit, and a lane's own
 // block 0 has one multiplicand of its first round known at compile time.
-// Uniforms are the top 24 bits / 2^24 (21-bit fields for the unit-sphere candidates): exactly
+// Uniforms are the top 24 bits / 2^24 (16-bit fields for the unit-sphere candidates): exactly
 // representable in FP32 and FP64.
 enum { P_CAM = 0, P_DISK = 1, P_SPHERE = 2, P_DIEL = 3, P_MEDIUM = 4 };
 #define RT_MAX_TRIALS 256  // rejection loops give up here so every lane reaches the exit
@@ -139,15 +139,16 @@ RT_DEV float u24(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; 
 // base.clj:182-186: the reduce seeds its accumulator with draw 0 and never tests it, then
 // keeps the first later draw with |v|^2 >= 1 (the inverse of the textbook test). Draw 0 is never
 // observable, so the keyed stream starts at draw 1 = candidate 0. One Philox block carries two
-// candidates of three 21-bit uniforms each (candidate j: block j >> 1, half j & 1): both are
-// evaluated without a branch, which halves the trips through this divergent loop.
+// candidates of three 16-bit uniforms each (candidate j: block j >> 1, words 2 (j & 1) and 2 (j & 1) + 1):
+// both are evaluated without a branch, which halves the trips through this divergent loop.
 RT_DEV V3 cube_point(uint32_t wa, uint32_t wb) {
-  // x, y: top 21 bits of each word; z: the 11 + 10 bits below them. (k - 2^20) * 2^-20 in [-1, 1)
-  const float S = 9.5367431640625e-7f;  // 2^-20
-  uint32_t xi = wa >> 11, yi = wb >> 11, zi = ((wa & 0x7FFu) << 10) | ((wb >> 1) & 0x3FFu);
-  // k * 2^-20 - 1 as one FMA on the converted field: k < 2^21 converts exactly and the result,
-  // (k - 2^20) / 2^20, is representable, so this is the same value as subtracting first
-  return mk(fmaf((float)xi, S, -1.0f), fmaf((float)yi, S, -1.0f), fmaf((float)zi, S, -1.0f));
+  // x, y: the two halves of the first word, z: the upper half of the second: 16-bit uniforms at cell centres,
+  // (k + 1/2) * 2^-15 - 1 in (-1, 1), symmetric about 0. A half-word converts with one instruction (the conversion
+  // reads the half in place), so a coordinate is a conversion and an FMA; 21-bit fields cost a shift or a mask more
+  // each, and two of the three straddled words.
+  const float S = 3.0517578125e-5f;        // 2^-15
+  const float C = -0.9999847412109375f;    // -(1 - 2^-16)
+  return mk(fmaf((float)(wa >> 16), S, C), fmaf((float)(wa & 0xFFFFu), S, C), fmaf((float)(wb >> 16), S, C));
 }
 template <class T>
 RT_DEV V3 random_in_unit_sphere(const Rng& g, uint32_t bounce, T& tally) {
@@ -665,8 +666,8 @@ RT_DEV void rect_pair(f2 k, f2 a0, f2 a1, f2 b0, f2 b1, int i0, int i1, const Ra
 }
 
 // Pair records fetched per scalar-memory round trip. Fewer means more trips and fewer SGPRs held
-// across them; measured: 2 is best where rects are the world (+2 % on the Cornell boxes over 3, 4 is
-// 4 % slower), 1 where a group holds a light or two among spheres (+2.5 % on random-scene).
+// across them; measured: while the Cornell room was loose rects, 2 (+2 % over 3, 4 is 4 % slower); with the room
+// and the boxes as slab tests, 1 everywhere (0.8 % over 2 on the Cornell box, +2.5 % on random-scene).
 template <class X>
 constexpr int pair_batch() { return (X::has(F_SMALL) || X::has(F_NOISE)) ? RT_PAIR_BATCH : 1; }
 
