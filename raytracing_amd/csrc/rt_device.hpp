@@ -665,6 +665,23 @@ RT_DEV void rect_pair(f2 k, f2 a0, f2 a1, f2 b0, f2 b1, int i0, int i1, const Ra
   }
 }
 
+// One rect alone (a run of odd length begins with a record whose two slots hold the same rect): the arithmetic of
+// one slot of rect_pair in plain FP32, the same operations on the same values, without the packed operands' set-up.
+template <int TYPE>
+RT_DEV void rect_single(float k, float a0, float a1, float b0, float b1, int idx, const RayX& r, float tmin, Best& best) {
+  float oc, ic, oa, da, ob, db;
+  if (TYPE == RT_PRIM_XY_RECT) { oc = r.o.z; ic = r.inv.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
+  else if (TYPE == RT_PRIM_XZ_RECT) { oc = r.o.y; ic = r.inv.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
+  else { oc = r.o.x; ic = r.inv.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
+  const float t = (k - oc) * ic;
+  const float a = fmaf(t, da, oa), b = fmaf(t, db, ob);
+  const float e1 = a - a0, e2 = a1 - a, e3 = b - b0, e4 = b1 - b, e5 = t - tmin, e6 = best.t - t;
+  const int sg = __float_as_int(e1) | __float_as_int(e2) | __float_as_int(e3) | __float_as_int(e4) | __float_as_int(e5) | __float_as_int(e6);
+  const bool ok = sg >= 0;
+  best.t = ok ? t : best.t;
+  best.prim = ok ? idx : best.prim;
+}
+
 // Pair records fetched per scalar-memory round trip. Fewer means more trips and fewer SGPRs held
 // across them; measured: while the Cornell room was loose rects, 2 (+2 % over 3, 4 is 4 % slower); with the room
 // and the boxes as slab tests, 1 everywhere (0.8 % over 2 on the Cornell box, +2.5 % on random-scene).
@@ -697,7 +714,12 @@ RT_DEV void brute_rects(const float RT_CONST* R, int n_xy, int n_xz, int n_yz, c
         const f2 k = {w[0], w[1]}, a0 = {w[2], w[3]}, a1 = {w[4], w[5]}, b0 = {w[6], w[7]}, b1 = {w[8], w[9]};
         const int i0 = __float_as_int(w[10]), i1 = __float_as_int(w[11]);
         tally.template add<RT_EV_RECT_TEST>(i0 == i1 ? 1 : 2);
-        if (q < p_xy) rect_pair<RT_PRIM_XY_RECT>(k, a0, a1, b0, b1, i0, i1, r, tmin, best);
+        if (i0 == i1) {  // (wave-uniform) one rect: the lights of the reference's worlds
+          if (q < p_xy) rect_single<RT_PRIM_XY_RECT>(w[1], w[3], w[5], w[7], w[9], i1, r, tmin, best);
+          else if (q < p_xz) rect_single<RT_PRIM_XZ_RECT>(w[1], w[3], w[5], w[7], w[9], i1, r, tmin, best);
+          else rect_single<RT_PRIM_YZ_RECT>(w[1], w[3], w[5], w[7], w[9], i1, r, tmin, best);
+        }
+        else if (q < p_xy) rect_pair<RT_PRIM_XY_RECT>(k, a0, a1, b0, b1, i0, i1, r, tmin, best);
         else if (q < p_xz) rect_pair<RT_PRIM_XZ_RECT>(k, a0, a1, b0, b1, i0, i1, r, tmin, best);
         else rect_pair<RT_PRIM_YZ_RECT>(k, a0, a1, b0, b1, i0, i1, r, tmin, best);
       }
