@@ -811,7 +811,9 @@ static int scene_create_impl(rt_ctx* ctx, const rt_scene_desc* d, int bvh_builde
         DPrim L = P;  // the record's copy: the primitive in its chain's space
         if (ptype == RT_PRIM_SPHERE) {
           for (int k = 0; k < 4; ++k) L.d[k] = pd[k];
+          L.d[4] = 1.0 / pd[3];  // base.clj:244 divides by the radius: the correctly rounded quotient, formed once
           sphere_fields(e, P.d);
+          P.d[4] = L.d[4];
         } else if (ptype == RT_PRIM_MOVING_SPHERE) {
           for (int k = 0; k < 9; ++k) L.d[k] = pd[k];
           sphere_fields(e, P.d);

@@ -68,7 +68,7 @@ struct DPrim {
   int32_t type;  // RT_PRIM_* in bits 0-3, index of the owning group in bits 4-31
   int32_t mat;   // material index of the description
   union {
-    double d[9];  // sphere: cx cy cz r | moving sphere: c0 xyz, c1 xyz, t0, t1, r
+    double d[9];  // sphere: cx cy cz r, then 1 / r | moving sphere: c0 xyz, c1 xyz, t0, t1, r
     float f[18];  // rect: a0 a1 b0 b1 k
   };
 };
