@@ -1002,11 +1002,11 @@ RT_DEV void prim_record(const DScene& S, int prim, const DPrimInfo& I, const Ray
       tally.template add<RT_EV_SPHERE_RECORD>();
       const DPrim RT_CONST& P = cptr(S.prims_rec)[prim];
       D3 c = sphere_center<!X::has(F_MOVING)>(P, type, r.tm);
-      // (a static sphere carries 1 / r, the same correctly rounded quotient the division gives; where moving spheres
-      // may be met the division stays, rather than a second operand and a select beside it)
-      double inv_r;
-      if constexpr (!X::has(F_MOVING)) inv_r = P.d[4];
-      else inv_r = 1.0 / sphere_radius<false>(P, type);
+      // (a static sphere carries 1 / r, the same correctly rounded quotient the division gives)
+      double inv_r = P.d[4];
+      if constexpr (X::has(F_MOVING)) {
+        if (type != RT_PRIM_SPHERE) inv_r = 1.0 / P.d[8];  // (rare: a branch, so that static spheres do not pay the division)
+      }
       D3 o64 = rayx_o64<X::has(F_CHAINS)>(r), d64 = rayx_d64<X::has(F_CHAINS)>(r);
       D3 pd = mkd(fma(root, d64.x, o64.x), fma(root, d64.y, o64.y), fma(root, d64.z, o64.z));
       D3 out = mkd((pd.x - c.x) * inv_r, (pd.y - c.y) * inv_r, (pd.z - c.z) * inv_r);
