@@ -6,7 +6,7 @@ instruction order across phase borders), walks the listing of one kernel in addr
 classes every instruction by what it costs to issue (cycles per wave64 instruction measured in
 profiles/r01_microbench_valu_rate*.txt). Loops are counted once (static), so the numbers say what a
 phase is MADE of, not how often it runs.
-Usage: python tools/isa_histogram.py [kernel-substring, default k_renderILj72ELb0]"""
+Usage: python tools/isa_histogram.py [kernel-substring, default k_renderILj4168ELb0]"""
 import os
 import re
 import subprocess
@@ -14,7 +14,7 @@ import sys
 from collections import Counter, OrderedDict
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-kernel = sys.argv[1] if len(sys.argv) > 1 else "k_renderILj72ELb0"
+kernel = sys.argv[1] if len(sys.argv) > 1 else "k_renderILj4168ELb0"
 asm = "/tmp/rt_kernels_marks.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fno-gpu-rdc",
                        "-DRT_PHASE_MARKS", *os.environ.get("RT_EXTRA_FLAGS", "").split(), "--cuda-device-only", "-S", os.path.join(ROOT, "raytracing_amd", "csrc", "rt_kernels.hip"), "-o", asm],
