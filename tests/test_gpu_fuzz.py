@@ -175,14 +175,16 @@ def _random_world(gpu_ctx, oracle, profile, seed, n_objects, knife):
     orc = oracle.hit_batch(flat, o, d, tm, medium_xi=xi)
     assert int(orc[:, 11].sum()) > n // 10
     _check_hits(dev, orc, o, d, knife, label=f"random world {seed} ({n_objects} objects, {flat.desc.n_prims} primitives, "
-                                             f"{nm} media, renders on {abi.VARIANT_NAMES[rv]})")
+                                             f"{nm} media, renders on {abi.VARIANT_NAMES[rv]})",
+                requery=lambda oo: oracle.hit_batch(flat, oo, d, tm, medium_xi=xi))
     for v in cover:
         assert sc.hit_batch(o, d, tm, medium_xi=xi, variant=v).tobytes() == dev.tobytes(), abi.VARIANT_NAMES[v]
     # the same rays over a window of t that cuts through the world (the t-min / t-max of base.clj:92-101)
     lo, hi = float(rng.uniform(1e-3, 0.2 * extent)) / float(np.median(np.linalg.norm(d, axis=1))), float(rng.uniform(0.6, 1.6))
     dev_w = sc.hit_batch(o, d, tm, t_min=lo, t_max=hi, medium_xi=xi)
     orc_w = oracle.hit_batch(flat, o, d, tm, t_min=lo, t_max=hi, medium_xi=xi)
-    _check_hits(dev_w, orc_w, o, d, knife, label=f"random world {seed}, t in [{lo:.3g}, {hi:.3g}]")
+    _check_hits(dev_w, orc_w, o, d, knife, label=f"random world {seed}, t in [{lo:.3g}, {hi:.3g}]",
+                requery=lambda oo: oracle.hit_batch(flat, oo, d, tm, t_min=lo, t_max=hi, medium_xi=xi))
     # per-sample radiance through the instantiation the render uses
     cfg = {"lookfrom": [0.0, 0.6 * extent, -2.2 * extent], "lookat": [0.0, 0.0, 0.0], "vfov": 50.0, "aperture": 0.1,
            "background": [0.5, 0.6, 0.8]}

@@ -27,12 +27,23 @@ TOL = 1e-5
 # grazes an edge, an exact tie): set from what is observed on the MI355X (profiles/r02_parity_stats.txt).
 # Observed: 0 of 20 000 probe rays in every world; path rays 4 of 9 249 (Cornell box, rays leaving
 # the rotated blocks along their faces), 0 elsewhere; scattered rays at most 3 of 12 301.
-# Largest error of a hit's distance t |d| among the records that agree, in ulps (2^-24) of the largest coordinate of
-# the ray's origin and the hit point. It is the error of the origin's offset from the surface (an ulp or two of the
-# coordinate after the FP32 chain motion) divided by the cosine of incidence, so grazing rays carry the largest.
-# Observed on the MI355X (profiles/r03_parity_stats.txt): at most 47 over every world of the suite (two media
-# worlds of the fuzz set), 44 on the Cornell box's path rays (99.99th percentile 17), 19 on its probe rays.
-DIST_ULPS = 128.0
+# Largest error of a hit's distance t |d| among the records that agree, DIVIDED BY THE CONDITION of the hit, in ulps
+# (2^-24) of the largest length involved: the coordinates of the ray's origin and of the hit point, and the distance
+# travelled. The FP32 path carries a ray's origin (in chain space too) to an ulp or two of its size; the distance to
+# the surface is that offset error times |d| |grad_o t| = 1 / cos(incidence) for a plane, which has no bound along a
+# grazing ray (a sweep of 1 200 random worlds met 205 ulps at a cosine of 0.003 where the suite's own worlds stay
+# below 47). The condition is measured, not taken from the record (the reference's rotate-y maps normals with +sin
+# in both rows, rotate.clj:37-42, so a record's normal is not the surface's): callers that can ask the oracle again
+# pass `requery`, the oracle's t for the same rays from origins moved by 8 ulps along each axis, and the finite
+# differences give grad_o t; callers that cannot (fixtures) fall back to the cosine against the record's normal. A
+# medium's hit lies a free-flight distance -log(xi) / density beyond the boundary (constant_medium.clj:32-36),
+# computed in FP32: its error is an ulp of that distance, which is why the distance travelled is among the lengths.
+# Observed on the MI355X with the condition measured (profiles/r03_parity_stats.txt, profiles/r03_sweeps.txt): at
+# most 9.1 over the suite (a fuzz world with a medium; 3.1 elsewhere), at most 5.4 over a sweep of 1 200 random worlds
+# whose plain distance errors reach 138 ulps. With the record's normal in place of the measurement (worlds without
+# rotations, fixtures): at most 47.
+DIST_ULPS = 32.0
+DIST_ULPS_FROM_NORMAL = 128.0
 KNIFE_PROBE = 5e-5
 KNIFE_PATH = 6e-4
 
@@ -46,7 +57,7 @@ def _uv_exempt(name, flat):
     return {int(flat.a_prim_mat[0])} if name == "final-scene" else set()
 
 
-def _check_hits(dev, orc, o32, d32, knife_budget, uv_exempt=(), label=None):
+def _check_hits(dev, orc, o32, d32, knife_budget, uv_exempt=(), label=None, requery=None):
     e = compare_hits(dev, orc, d32)
     for m in uv_exempt:
         e["uv"] = np.where(orc[:, 10].astype(int) == m, 0.0, e["uv"])
@@ -61,16 +72,35 @@ def _check_hits(dev, orc, o32, d32, knife_budget, uv_exempt=(), label=None):
     # translate.clj:11, rotate.clj:18-22) to half an ulp of their size, so the DISTANCE to the hit, t |d|, is off
     # by a few ulps of the largest coordinate involved however short the distance is. For a hit an inch from a
     # ray's origin 800 units from the world's, that is a large error relative to t and none relative to the world.
-    dist_err = np.abs(dev["t"].astype(np.float64) - orc[:, 0]) * np.linalg.norm(d32.astype(np.float64), axis=1)
-    size = np.maximum(np.maximum(np.abs(o32).max(axis=1), np.abs(orc[:, 1:4]).max(axis=1)), 1.0)
+    d_len = np.linalg.norm(d32.astype(np.float64), axis=1)
+    dist_err = np.abs(dev["t"].astype(np.float64) - orc[:, 0]) * d_len
+    size = np.maximum(np.maximum(np.abs(o32).max(axis=1), np.abs(orc[:, 1:4]).max(axis=1)), np.maximum(np.abs(orc[:, 0]) * d_len, 1.0))
     dist_ulps = dist_err / (size * 2.0 ** -24)
-    assert not good.any() or dist_ulps[good].max() <= DIST_ULPS, (
-        f"a hit's distance is off by {dist_ulps[good].max():.1f} ulps of its largest coordinate (bound {DIST_ULPS})")
+    if requery is not None:
+        grad2 = np.zeros(n)
+        known = np.ones(n, bool)
+        for k in range(3):
+            o_k = o32.copy()
+            o_k[:, k] += (size * 2.0 ** -21).astype(np.float32)
+            delta = o_k[:, k].astype(np.float64) - o32[:, k].astype(np.float64)
+            again = requery(o_k)
+            same = (again[:, 11] > 0.5) & (again[:, 10] == orc[:, 10]) & (delta != 0.0)
+            known &= same
+            grad2 += np.where(same, (again[:, 0] - orc[:, 0]) / np.where(delta != 0.0, delta, 1.0), 0.0) ** 2
+        cond = np.where(known, np.maximum(np.sqrt(grad2) * d_len, 1.0), np.inf)  # (a record whose neighbours hit something else: no claim)
+    else:
+        cos_inc = np.abs((orc[:, 4:7] * d32).sum(axis=1)) / np.maximum(np.linalg.norm(orc[:, 4:7], axis=1) * d_len, 1e-300)
+        cond = 1.0 / np.maximum(np.minimum(cos_inc, 1.0), 1e-300)
+    offset_ulps = dist_ulps / cond
+    bound = DIST_ULPS if requery is not None else DIST_ULPS_FROM_NORMAL
+    assert not good.any() or offset_ulps[good].max() <= bound, (
+        f"a hit's distance is off by {offset_ulps[good].max():.1f} ulps of its largest length per unit of condition (bound {bound})")
     if label and good.any():
         q = lambda a: float(np.quantile(a[good], 0.9999))
         print(f"[parity] {label}: {n} rays, {int(both.sum())} hits; knife-edge {n_bad} (hit/miss {e['hit_mismatch']}); "
               f"t relative to |t| alone: 99.99th pct {q(e['t']):.2e} max {e['t'][good].max():.2e}; "
-              f"distance error in ulps of the largest coordinate: 99.99th pct {q(dist_ulps):.2f} max {dist_ulps[good].max():.2f}; "
+              f"distance error in ulps of the largest length: 99.99th pct {q(dist_ulps):.2f} max {dist_ulps[good].max():.2f}, "
+              f"per unit of condition ({'measured' if requery is not None else 'from the normal'}): 99.99th pct {q(offset_ulps):.2f} max {offset_ulps[good].max():.2f}; "
               f"99.99th pct t {q(t_err):.2e} p {q(e['p']):.2e} n {q(e['n']):.2e} uv {q(e['uv']):.2e}; "
               f"max t {t_err[good].max():.2e} p {e['p'][good].max():.2e} n {e['n'][good].max():.2e} uv {e['uv'][good].max():.2e}")
     if n_bad > max(1, int(knife_budget * n)):
@@ -95,7 +125,8 @@ def test_hit_records_probe_rays(gpu_ctx, oracle, name):
     dev = sc.hit_batch(o, d, tm, medium_xi=xi)
     orc = oracle.hit_batch(flat, o, d, tm, medium_xi=xi)
     assert int(orc[:, 11].sum()) > n // 20
-    _check_hits(dev, orc, o, d, KNIFE_PROBE, _uv_exempt(name, flat), label=f"{name} probe rays")
+    _check_hits(dev, orc, o, d, KNIFE_PROBE, _uv_exempt(name, flat), label=f"{name} probe rays",
+                requery=lambda oo: oracle.hit_batch(flat, oo, d, tm, medium_xi=xi))
     # media skipped on both sides (medium_xi = NULL)
     if nm:
         dev = sc.hit_batch(o, d, tm)
@@ -197,7 +228,8 @@ def test_hit_records_path_rays(gpu_ctx, oracle, name):
     xi = np.array(xis, dtype=np.float32) if nm else None
     dev = sc.hit_batch(o32, d32, t32, medium_xi=xi)
     orc = oracle.hit_batch(flat, o32, d32, t32, medium_xi=xi)
-    _check_hits(dev, orc, o32, d32, KNIFE_PATH, _uv_exempt(name, flat), label=f"{name} path rays")
+    _check_hits(dev, orc, o32, d32, KNIFE_PATH, _uv_exempt(name, flat), label=f"{name} path rays",
+                requery=lambda oo: oracle.hit_batch(flat, oo, d32, t32, medium_xi=xi))
     sc.close()
 
 
