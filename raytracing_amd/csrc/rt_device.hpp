@@ -1288,15 +1288,19 @@ RT_DEV bool closest_hit(const X& ctx, const Ray& wr, float tmin, float tmax, con
 // ------------------------------------------------------------------------------- textures
 RT_DEV float hermite(float x) { return x * x * (3.0f - 2.0f * x); }
 
-// noise.clj:39-58 + :21-33. The cell index and fraction come from FP64 (p * 2^k is exact there),
-// the rest is FP32. Both Hermite passes and the OR of the three permutation entries are the
+// noise.clj:39-58 + :21-33. Both Hermite passes and the OR of the three permutation entries are the
 // reference's. Tables are read from LDS.
+// The point is an FP32 hit point times a power of two (perlin_turb), so cell and fraction come out of FP32
+// exactly as they would out of FP64: the floor is exact, and p - floor(p) is one correctly rounded subtraction
+// of two exact operands either way (the FP64 difference is exact, or within 2^-29 of 1 and rounds to 1 like
+// the FP32 one). Sixty FP64-rate instructions per octave (three of them conversions to 64-bit integers)
+// become twelve FP32 ones with the same results bit for bit.
 template <class X, class T>
-RT_DEV float perlin_noise(const X& ctx, int pid, D3 p, T& tally) {
+RT_DEV float perlin_noise(const X& ctx, int pid, V3 p, T& tally) {
   tally.template add<RT_EV_PERLIN_NOISE>();
-  double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
-  float u = hermite((float)(p.x - fx)), v = hermite((float)(p.y - fy)), w = hermite((float)(p.z - fz));
-  int i = (int)(long long)fx, j = (int)(long long)fy, k = (int)(long long)fz;
+  const float fx = __builtin_floorf(p.x), fy = __builtin_floorf(p.y), fz = __builtin_floorf(p.z);
+  float u = hermite(p.x - fx), v = hermite(p.y - fy), w = hermite(p.z - fz);
+  int i = (int)fx, j = (int)fy, k = (int)fz;
   const uint8_t* perm = ctx.lds_perlin_perm + pid * 768;
   // (a gradient is three floats at a 16-byte stride: three registers per corner in flight, not four)
   struct G3 { float x, y, z, pad; };
@@ -1329,19 +1333,21 @@ RT_DEV float perlin_noise(const X& ctx, int pid, D3 p, T& tally) {
 template <class X, class T>
 RT_DEV float perlin_turb(const X& ctx, int pid, V3 p, int depth, T& tally) {
   float acc = 0.f, weight = 1.f;
-  D3 tp = tod(p);
+  V3 tp = p;
   for (int i = 0; i < depth; ++i) {
     acc = fmaf(weight, perlin_noise(ctx, pid, tp, tally), acc);
     weight *= 0.5f;
-    tp = mkd(tp.x * 2.0, tp.y * 2.0, tp.z * 2.0);
+    tp = mk(tp.x * 2.0f, tp.y * 2.0f, tp.z * 2.0f);  // exact
   }
   return fabsf(acc);
 }
 
 // sign of sin(x) for FP64 x = 10 * coordinate: negative iff floor(x / pi) is odd.
 RT_DEV bool sin_negative(double x) {
-  double q = floor(x * 0.3183098861837907);
-  return ((long long)q & 1LL) != 0;
+  const double q = floor(x * 0.3183098861837907);
+  // q odd: half of it is not a whole number (a conversion to a 64-bit integer is a dozen instructions here)
+  const double h = q * 0.5;
+  return h != floor(h);
 }
 
 // A hit point ON a coordinate plane through the origin (a rect with k = 0): the reference's point o + t d
