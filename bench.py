@@ -264,8 +264,9 @@ def main():
         if rank == 0:
             got, want = float(shard.double().sum()), float(check[0])
             tol = (1e-9 if args.split == "tile" else 1e-5) * max(abs(want), 1.0)
-            assert abs(got - want) <= tol, f"reduced frame sums to {got!r}, the ranks' shards to {want!r}"
-            reduce_check = {"sum_of_reduced_frame": got, "sum_of_shard_sums": want, "tolerance": tol, "ok": True}
+            # (a mismatch fails the run AFTER the JSON line is out: the line then says "ok": false and the exit code says so too)
+            reduce_check = {"sum_of_reduced_frame": got, "sum_of_shard_sums": want, "tolerance": tol,
+                            "ok": bool(abs(got - want) <= tol)}
 
     # Roofline numerator: event counts of the SAME kernel from its counting build (a separate,
     # untimed launch at reduced spp; FLOP per sample does not depend on spp beyond MC noise).
@@ -365,6 +366,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if reduce_check is not None and not reduce_check["ok"]:
+        sys.exit(f"reduced frame sums to {reduce_check['sum_of_reduced_frame']!r}, the ranks' shards to "
+                 f"{reduce_check['sum_of_shard_sums']!r}")
 
 
 if __name__ == "__main__":
