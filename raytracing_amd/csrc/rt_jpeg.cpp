@@ -62,13 +62,15 @@ struct Huff {
   int32_t mincode[18], maxcode[18], valptr[18];
   // fast path: codes of up to 9 bits resolved by one lookup (value | length << 8), 0 = longer code
   uint16_t fast[512];
-  void build() {
+  // false: the code lengths do not describe a prefix code (more codes of some length than that length has left)
+  bool build() {
     int code = 0, k = 0;
     for (int l = 1; l <= 16; ++l) {
       valptr[l] = k;
       mincode[l] = code;
       code += bits[l];
       k += bits[l];
+      if (code > (1 << l)) return false;
       maxcode[l] = bits[l] ? code - 1 : -1;
       code <<= 1;
     }
@@ -83,6 +85,7 @@ struct Huff {
       code <<= 1;
     }
     defined = true;
+    return true;
   }
 };
 
@@ -223,7 +226,7 @@ struct Decoder {
       }
       if (total > 256) bad("Huffman table with more than 256 codes");
       for (int i = 0; i < total; ++i) h.vals[i] = (uint8_t)u8();
-      h.build();
+      if (!h.build()) bad("Huffman table whose code lengths are not a prefix code");
       len -= 17 + total;
     }
     if (len != 0) bad("Huffman table segment length");
@@ -620,7 +623,7 @@ struct Decoder {
             adobe = true;
             adobe_transform = p[pos + 11];
           }
-          if (pos + (size_t)(len - 2) > n) bad("segment longer than the file");
+          if (len < 2 || pos + (size_t)(len - 2) > n) bad("segment longer than the file");
           pos += (size_t)(len - 2);
           break;
         }

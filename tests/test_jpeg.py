@@ -96,3 +96,57 @@ def test_what_is_not_read_is_refused_with_a_reason():
     small = np.full(100, 7, np.uint8)
     assert L.rt_image_decode_jpeg(data, len(data), C.byref(w), C.byref(h), small.ctypes.data, small.nbytes) == abi.RT_ERR_ARG
     assert (w.value, h.value) == (1024, 512) and (small == 7).all()
+
+
+def _mutations(data, rng, n):
+    """Truncations, overwritten bytes (anywhere and in the headers), planted markers, pieces cut out."""
+    for _ in range(n):
+        d = bytearray(data)
+        mode = int(rng.integers(0, 5))
+        if mode == 0:
+            d = d[: int(rng.integers(0, len(d) + 1))]
+        elif mode == 1:
+            for _ in range(int(rng.integers(1, 9))):
+                d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))
+        elif mode == 2:
+            for _ in range(int(rng.integers(1, 5))):
+                d[int(rng.integers(0, min(len(d), 700)))] = int(rng.integers(0, 256))
+        elif mode == 3:
+            q = int(rng.integers(0, len(d) - 1))
+            d[q], d[q + 1] = 0xFF, int(rng.integers(0xC0, 0x100))
+        else:
+            q = int(rng.integers(0, len(d)))
+            del d[q: q + int(rng.integers(1, 65))]
+        yield bytes(d)
+
+
+def test_a_huffman_table_that_is_not_a_prefix_code_is_refused():
+    """Three codes of length one cannot exist: such a table used to overrun the decoder's nine-bit lookup table."""
+    buf = io.BytesIO()
+    Image.fromarray(_picture(32, 32, 5)).save(buf, "JPEG", quality=80)
+    data = bytearray(buf.getvalue())
+    at = data.index(b"\xff\xc4")          # the first DHT segment: marker, length, class | id, sixteen counts
+    data[at + 5] = 3
+    with pytest.raises(lib.RtError) as e:
+        lib.decode_jpeg(bytes(data))
+    assert e.value.code == abi.RT_ERR_ARG and "prefix code" in str(e.value)
+
+
+@pytest.mark.parametrize("kw", [dict(quality=85, subsampling=2), dict(quality=40, subsampling=1, progressive=True),
+                                dict(quality=85, subsampling=0, restart_marker_blocks=2)])
+def test_mutated_files_never_take_the_library_down(kw):
+    """Every mutation either decodes to a picture of the size its header names or is refused with a code and a
+    message (tools/fuzz/jpeg_fuzz.cpp runs the same mutations under AddressSanitizer)."""
+    buf = io.BytesIO()
+    Image.fromarray(_picture(48, 40, 9)).save(buf, "JPEG", **kw)
+    rng = np.random.default_rng(len(buf.getvalue()))
+    decoded = refused = 0
+    for bad in _mutations(buf.getvalue(), rng, 400):
+        try:
+            got = lib.decode_jpeg(bad)
+            assert got.ndim == 3 and got.shape[2] == 3 and got.shape[0] > 0 and got.shape[1] > 0
+            decoded += 1
+        except lib.RtError as e:
+            assert e.code in (abi.RT_ERR_ARG, abi.RT_ERR_UNSUPPORTED, abi.RT_ERR_OOM) and str(e)
+            refused += 1
+    assert decoded + refused == 400 and refused > 0
