@@ -16,7 +16,7 @@ SAN="-Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined"
    -Wl,-rpath,'$ORIGIN' -o gpurun_tmp/scene_fuzz
 /opt/rocm/bin/hipcc -O1 -g -std=c++17 --offload-arch=gfx950 -w $SAN tools/fuzz/api_walk.cpp -Lgpurun_tmp -lrtmi_asan \
    -Wl,-rpath,'$ORIGIN' -o gpurun_tmp/api_walk
-g++ -O1 -g -std=c++17 -fsanitize=address,undefined -DRT_JPEG_FUZZ_STANDALONE tools/fuzz/jpeg_fuzz.cpp raytracing_amd/csrc/rt_jpeg.cpp -o gpurun_tmp/jpeg_fuzz
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined tools/fuzz/jpeg_fuzz.cpp raytracing_amd/csrc/rt_jpeg.cpp -o gpurun_tmp/jpeg_fuzz
 python3 - <<'PY'
 import sys
 sys.path.insert(0, ".")
