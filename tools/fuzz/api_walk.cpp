@@ -16,6 +16,7 @@
 #include <random>
 #include <vector>
 #include "../../include/rtmi.h"
+extern "C" int __lsan_do_recoverable_leak_check();
 
 #define OK(call)                                                                                   \
   do {                                                                                             \
@@ -224,7 +225,45 @@ int main(int argc, char** argv) {
     if (rt_scene_create(ctx, nullptr, &sc) == RT_OK) { fprintf(stderr, "a NULL description was accepted\n"); return 1; }
     if (rt_scene_create_from_file(ctx, "/nonexistent/file", &sc) == RT_OK) { fprintf(stderr, "a missing file was accepted\n"); return 1; }
   }
+  // Worlds come and go without taking device memory with them. (The runtime's allocator keeps some of what it is handed
+  // back - free memory sinks by some tens of MB over the first hundred rounds and then stays - so what is checked is that
+  // the second half of the rounds loses far less than the first: a leak per round would lose as much.)
+  if (argc > 1 && strcmp(argv[1], "--") != 0) {
+    size_t free0 = 0, free_half = 0, free1 = 0, total = 0;
+    rt_scene* sc = nullptr;
+    OK(rt_scene_create_from_file(ctx, argv[1], &sc));  // (first use pays for what the runtime keeps: modules, queues)
+    rt_scene_destroy(sc);
+    HIP(hipDeviceSynchronize());
+    HIP(hipMemGetInfo(&free0, &total));
+    const int rounds = getenv("RT_ROUNDS") ? atoi(getenv("RT_ROUNDS")) : 100;
+    for (int round = 0; round < rounds; ++round) {
+      for (int b = 1; b < argc && strcmp(argv[b], "--") != 0; ++b) {
+        OK(rt_scene_create_from_file(ctx, argv[b], &sc));
+        const rt_camera cam = a_camera();
+        rt_params p = some_params(40, 24, 2);
+        std::vector<uint32_t> argb(40 * 24);
+        OK(rt_render(ctx, sc, &cam, &p, nullptr, argb.data(), nullptr));
+        rt_scene_destroy(sc);
+      }
+      if (round == rounds / 2) {
+        HIP(hipDeviceSynchronize());
+        HIP(hipMemGetInfo(&free_half, &total));
+      }
+    }
+    HIP(hipDeviceSynchronize());
+    HIP(hipMemGetInfo(&free1, &total));
+    const long long first = (long long)free0 - (long long)free_half, second = (long long)free_half - (long long)free1;
+    printf("device memory free over %d rounds of create-render-destroy of every scene: first half lost %lld bytes, second half %lld\n",
+           rounds, first, second);
+    if (second > first / 2 + (16 << 20)) { fprintf(stderr, "device memory is leaking: %lld bytes in the second half of the rounds\n", second); return 1; }
+  }
   rt_shutdown(ctx);
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+  // host allocations still reachable from nowhere (the runtime's own are reported too: read the frames)
+  if (getenv("RT_LEAK_CHECK")) __lsan_do_recoverable_leak_check();
+#endif
+#endif
   printf("done\n");
   fflush(stdout);
   _exit(0);  // (ROCm's sanitizer runtime trips over its own device allocator when the process unwinds normally)
