@@ -8,7 +8,7 @@ reaches only by editing its source.
 from __future__ import annotations
 
 import random
-from typing import Optional
+from typing import Optional, Sequence
 
 import numpy as np
 
@@ -51,19 +51,51 @@ def write_ppm(path: str, argb: np.ndarray) -> None:
 
 def main(samples: int = 30, scene: str = "final-scene", image_width: int = 200, aspect_ratio: float = 1.0,
          max_depth: int = 50, scene_seed: int = 1, seed: int = 0x5EED0001, device: int = 0,
-         output: Optional[str] = None):
-    """(-main :samples n) on the GPU. Returns (argb (H, W) uint32 with row 0 = bottom, stats)."""
+         output: Optional[str] = None, devices: Optional[Sequence[int]] = None, split: str = "tile"):
+    """(-main :samples n) on the GPU. Returns (argb (H, W) uint32 with row 0 = bottom, stats).
+    devices: several GPUs of this node behind one call (rt_multi_*: what the reference's one thread per row and its
+    latch become, core.clj:109-128), the frame split by tiles ("tile": bit-identical to one GPU) or by samples
+    ("sample"); None or one id renders on `device` alone."""
     image_height = int(image_width / aspect_ratio)  # core.clj:54
     cfg, flat = setup(scene, scene_seed)
     cam = build_camera(cfg, aspect_ratio)
     params = abi.make_params(image_width, image_height, samples, max_depth, cfg["background"], seed)
-    ctx = lib.Context(device)
-    sc = ctx.scene(flat)
-    try:
-        _, argb, stats = sc.render(cam, params, want_rgb=False, want_argb=True)
-    finally:
-        sc.close()
-        ctx.close()
+    if split not in ("tile", "sample"):
+        raise ValueError(f"split must be 'tile' or 'sample', not {split!r}")
+    if devices is not None and len(devices) > 1:
+        mctx = lib.MultiContext(list(devices))
+        msc = mctx.scene(flat)
+        try:
+            _, argb, stats = msc.render(cam, params, abi.RT_SPLIT_TILES if split == "tile" else abi.RT_SPLIT_SAMPLES)
+        finally:
+            msc.close()
+            mctx.close()
+    else:
+        ctx = lib.Context(devices[0] if devices else device)
+        sc = ctx.scene(flat)
+        try:
+            _, argb, stats = sc.render(cam, params, want_rgb=False, want_argb=True)
+        finally:
+            sc.close()
+            ctx.close()
     if output:
         write_ppm(output, argb)
     return argb, stats
+
+
+if __name__ == "__main__":  # python -m raytracing_amd.core --samples 10 [--scene cornell-box --width 400 --gpus 0,1 --output out.ppm]
+    import argparse
+
+    ap = argparse.ArgumentParser(description="(-main :samples n) of core.clj:50-51 on the GPU")
+    ap.add_argument("--samples", type=int, default=30)
+    ap.add_argument("--scene", default="final-scene", choices=sorted(scenes.SCENES))
+    ap.add_argument("--width", type=int, default=200)
+    ap.add_argument("--aspect", type=float, default=1.0)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--gpus", default="0", help="device ids, comma-separated; more than one renders through rt_multi_*")
+    ap.add_argument("--split", default="tile", choices=["tile", "sample"])
+    ap.add_argument("--output", default=None, help="write the frame as a binary PPM")
+    a = ap.parse_args()
+    ids = [int(v) for v in a.gpus.split(",")]
+    _, st = main(a.samples, a.scene, a.width, a.aspect, a.depth, devices=ids, split=a.split, output=a.output)
+    print(f"{a.scene} {a.width}x{int(a.width / a.aspect)} @{a.samples}: {st['samples']} samples, {st['rays']} rays, kernel {st['kernel_ms']:.2f} ms")

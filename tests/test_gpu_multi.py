@@ -5,6 +5,8 @@ A box with ONE device runs the one-device path and the fan-out rehearsed with on
 times (shards, ordering, the sum on the first device, the post-process). The RCCL reduce between
 DISTINCT devices runs in test_distinct_devices_reduce_over_rccl wherever two or more devices are visible
 and is skipped, saying so, where there is one."""
+import os
+
 import numpy as np
 import pytest
 
@@ -123,3 +125,29 @@ def test_rccl_loads_and_reduces_on_one_rank(gpu_ctx):
     L = lib.load()
     rc = L.rt_multi_selftest_rccl(0)
     assert rc == 0, L.rt_multi_last_error().decode()
+
+
+def test_main_over_several_devices_gives_the_frame_of_one(tmp_path):
+    """raytracing_amd.core.main with `devices` (the :gpus key the front door gains): a tile split over one device named
+    three times returns the single-device frame bit for bit, a sample split the same picture to within one 8-bit step,
+    and the command line writes the same frame as a PPM."""
+    import subprocess
+    import sys
+    from raytracing_amd import core
+    one, st1 = core.main(samples=6, scene="cornell-box", image_width=72)
+    tiles, st3 = core.main(samples=6, scene="cornell-box", image_width=72, devices=[0, 0, 0], split="tile")
+    assert np.array_equal(one, tiles) and st3["samples"] == st1["samples"] == 72 * 72 * 6
+    slices, _ = core.main(samples=6, scene="cornell-box", image_width=72, devices=[0, 0], split="sample")
+    ch = np.array([16, 8, 0])[:, None, None]
+    assert np.abs(((one >> ch) & 255).astype(int) - ((slices >> ch) & 255).astype(int)).max() <= 1
+    with pytest.raises(ValueError):
+        core.main(samples=1, devices=[0, 0], split="rows")
+    out = tmp_path / "frame.ppm"
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    r = subprocess.run([sys.executable, "-m", "raytracing_amd.core", "--samples", "6", "--scene", "cornell-box", "--width", "72",
+                        "--gpus", "0,0,0", "--output", str(out)], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-600:]
+    data = out.read_bytes()
+    assert data.startswith(b"P6\n72 72\n255\n")
+    px = np.frombuffer(data[len(b"P6\n72 72\n255\n"):], np.uint8).reshape(72, 72, 3)[::-1]
+    assert np.array_equal(px[:, :, 0], (one >> 16) & 255) and np.array_equal(px[:, :, 2], one & 255)
