@@ -7,7 +7,9 @@
 #include "../../include/rtmi.h"
 #include "rt_scene.h"
 
+#ifndef RT_BLOCK
 #define RT_BLOCK 256  // threads per workgroup of the path kernels (4 waves)
+#endif
 
 // Trees of up to this many nodes keep the second half of each packed node in LDS (see bvh_traverse).
 #ifndef RT_LDS_NODE_MAX
