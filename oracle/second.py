@@ -1,0 +1,370 @@
+"""A SECOND restatement of the reference's path, independent of oracle.cpp: pure Python over the records of the host
+mirror (raytracing_amd/hittables.py, materials.py, texture.py), written from the Clojure text form by form — protocol
+dispatch as a type switch, `reduce` as a loop, the recursion of BvhNode and ray-color kept as recursion, doubles
+throughout. Test infrastructure only (tests/test_oracle_second.py holds oracle.cpp against it on every reference
+world); far too slow for anything else. Parity unpinned, like oracle.cpp: the reference ships no tests or fixtures,
+so two restatements that agree, and the hand-derived known answers, are all the pinning there is.
+
+The one source of randomness is passed in: `rng` is any callable returning the next uniform of [0, 1) (Math/random,
+base.clj:127; `rand`, materials.clj:56), so a test scripts the draws.
+"""
+from __future__ import annotations
+
+import math
+
+from raytracing_amd import hittables as H
+from raytracing_amd import materials as M
+from raytracing_amd import texture as T
+
+INF = float("inf")
+
+
+# ---- base.clj:11-46 --------------------------------------------------------------------------------------------------
+def dot(a, b): return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+def vmul(v, k): return [v[0] * k, v[1] * k, v[2] * k]
+def vadd(a, b): return [a[0] + b[0], a[1] + b[1], a[2] + b[2]]
+def vsub(a, b): return [a[0] - b[0], a[1] - b[1], a[2] - b[2]]
+def vd(v, k): return vmul(v, 1 / k)                      # base.clj:30-31: times the reciprocal
+def length_squared(v): return v[0] * v[0] + v[1] * v[1] + v[2] * v[2]
+def length(v): return math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+def unit_vector(v): return vd(v, length(v))
+def neg(v): return [-v[0], -v[1], -v[2]]
+
+
+def jdiv(a, b):
+    """JVM double division: x / 0.0 is an infinity or NaN, never an exception."""
+    try:
+        return a / b
+    except ZeroDivisionError:
+        if a != a or a == 0.0:
+            return float("nan")
+        return math.copysign(INF, a) * math.copysign(1.0, b)
+
+
+class Ray:  # ray.clj:8
+    __slots__ = ("orig", "dir", "time_")
+
+    def __init__(self, orig, dir, time_=0.0):
+        self.orig, self.dir, self.time_ = orig, dir, time_
+
+
+def ray_at(r, t):  # base.clj:166-167
+    return vadd(r.orig, vmul(r.dir, t))
+
+
+def set_face_normal(r, outward_normal):  # base.clj:171-174
+    front_face = dot(r.dir, outward_normal) < 0
+    return front_face, (outward_normal if front_face else neg(outward_normal))
+
+
+# ---- base.clj:59-76 --------------------------------------------------------------------------------------------------
+def aabb_hit(box, r, t_min, t_max):
+    for a in range(3):
+        inv_d = jdiv(1.0, r.dir[a])
+        t0 = inv_d * (box.minimum[a] - r.orig[a])
+        t1 = inv_d * (box.maximum[a] - r.orig[a])
+        if inv_d < 0.0:
+            t0, t1 = t1, t0
+        t_min = t0 if t0 > t_min else t_min
+        t_max = t1 if t1 < t_max else t_max
+        if t_max <= t_min:
+            return False
+    return True
+
+
+def get_sphere_uv(p):  # base.clj:222-227
+    x, y, z = p
+    try:
+        theta = math.acos(-y)
+    except ValueError:      # |y| > 1: Math/acos gives NaN
+        theta = float("nan")
+    phi = math.atan2(-z, x) + math.pi
+    return phi / (2 * math.pi), theta / math.pi
+
+
+def _sphere_hit(center, radius, mat, r, t_min, t_max):  # base.clj:234-252 / :274-292
+    oc = vsub(r.orig, center)
+    a = length_squared(r.dir)
+    half_b = dot(oc, r.dir)
+    c = length_squared(oc) - math.pow(radius, 2)
+    discriminant = math.pow(half_b, 2) - a * c
+    if not discriminant > 0:
+        return None
+    sqrtd = math.sqrt(discriminant)
+    root = jdiv(-half_b - sqrtd, a)
+    if not (t_max > root > t_min):
+        root = jdiv(-half_b + root, a)      # base.clj:247: the first root, not the square root, is added
+        if not (t_max > root > t_min):
+            return None
+    outward_normal = vd(vsub(ray_at(r, root), center), radius)
+    u, v = get_sphere_uv(outward_normal)
+    front_face, normal = set_face_normal(r, outward_normal)
+    return dict(p=ray_at(r, root), normal=normal, mat_ptr=mat, t=root, u=u, v=v, front_face=front_face)
+
+
+def _rect_hit(o, r, t_min, t_max, axis_k, axis_a, axis_b, a0, a1, b0, b1, outward_normal):  # rectangles.clj:15-37,52-74,89-111
+    t = jdiv(o.k - r.orig[axis_k], r.dir[axis_k])
+    if t < t_min or t > t_max:
+        return None
+    a = r.orig[axis_a] + t * r.dir[axis_a]
+    b = r.orig[axis_b] + t * r.dir[axis_b]
+    if a < a0 or a > a1 or b < b0 or b > b1:
+        return None
+    u = jdiv(a - a0, a1 - a0)
+    v = jdiv(b - b0, b1 - b0)
+    front_face, normal = set_face_normal(r, outward_normal)
+    return dict(p=ray_at(r, t), normal=normal, mat_ptr=o.mp, t=t, u=u, v=v, front_face=front_face)
+
+
+def _list_hit(objects, r, t_min, t_max, rng):  # base.clj:92-101
+    record, closest_so_far = None, t_max
+    for hittable in objects:
+        rec = hit(hittable, r, t_min, closest_so_far, rng)
+        if rec:
+            closest_so_far = rec["t"]
+            record = rec
+    return record
+
+
+def hit(o, r, t_min, t_max, rng):
+    """(hit o r t-min t-max rec) -> a record (dict) or None. rng: callable(medium) -> the uniform of constant_medium.clj:32."""
+    if isinstance(o, H.Sphere):
+        return _sphere_hit(o.center, o.radius, o.mat_ptr, r, t_min, t_max)
+    if isinstance(o, H.MovingSphere):
+        # base.clj:298-302
+        center = vadd(o.center0, vmul(vsub(o.center1, o.center0), jdiv(r.time_ - o.time0, o.time1 - o.time0)))
+        return _sphere_hit(center, o.radius, o.mat_ptr, r, t_min, t_max)
+    if isinstance(o, H.XYRect):
+        return _rect_hit(o, r, t_min, t_max, 2, 0, 1, o.x0, o.x1, o.y0, o.y1, [0.0, 0.0, 1.0])
+    if isinstance(o, H.XZRect):
+        return _rect_hit(o, r, t_min, t_max, 1, 0, 2, o.x0, o.x1, o.z0, o.z1, [0.0, 1.0, 0.0])
+    if isinstance(o, H.YZRect):
+        return _rect_hit(o, r, t_min, t_max, 0, 1, 2, o.y0, o.y1, o.z0, o.z1, [1.0, 0.0, 0.0])
+    if isinstance(o, H.HittableList):
+        return _list_hit(o.objects, r, t_min, t_max, rng)
+    if isinstance(o, H.Box):  # box.clj:10-11
+        return _list_hit(o.sides, r, t_min, t_max, rng)
+    if isinstance(o, H.BvhNode):  # base.clj:118-122
+        if not aabb_hit(o.box, r, t_min, t_max):
+            return None
+        hit_left = hit(o.left, r, t_min, t_max, rng)
+        hit_right = hit(o.right, r, t_min, hit_left["t"] if hit_left else t_max, rng)
+        return hit_right or hit_left
+    if isinstance(o, H.RotateY):  # rotate.clj:11-47
+        s, c = o.sin_theta, o.cos_theta
+        ox, oy, oz = r.orig
+        dx, dy, dz = r.dir
+        rotated_r = Ray([c * ox - s * oz, oy, s * ox + c * oz], [c * dx - s * dz, dy, s * dx + c * dz], r.time_)
+        rec = hit(o.ptr, rotated_r, t_min, t_max, rng)
+        if not rec:
+            return None
+        px, py, pz = rec["p"]
+        nx, ny, nz = rec["normal"]
+        new_p = [c * px + s * pz, py, s * px + c * pz]          # (+ in both rows, as the reference has it)
+        new_normal = [c * nx + s * nz, ny, s * nx + c * nz]
+        front_face, normal = set_face_normal(rotated_r, new_normal)
+        return dict(rec, p=new_p, front_face=front_face, normal=normal)
+    if isinstance(o, H.Translate):  # translate.clj:10-17
+        moved_r = Ray(vsub(r.orig, o.offset), r.dir, r.time_)
+        rec = hit(o.ptr, moved_r, t_min, t_max, rng)
+        if not rec:
+            return None
+        front_face, normal = set_face_normal(moved_r, rec["normal"])
+        return dict(rec, p=vadd(rec["p"], o.offset), front_face=front_face, normal=normal)
+    if isinstance(o, H.ConstantMedium):  # constant_medium.clj:11-44
+        rec1 = hit(o.boundary, r, -INF, INF, rng)
+        if not rec1:
+            return None
+        rec2 = hit(o.boundary, r, rec1["t"] + 0.0001, INF, rng)
+        if not rec2:
+            return None
+        t1 = t_min if rec1["t"] < t_min else rec1["t"]
+        t2 = t_max if rec2["t"] > t_max else rec2["t"]
+        if not t1 < t2:
+            return None
+        if t1 < 0:
+            t1 = 0
+        ray_length = length(r.dir)
+        distance_inside_boundary = (t2 - t1) * ray_length
+        hit_distance = o.neg_inv_density * math.log(rng(o))
+        if not hit_distance <= distance_inside_boundary:
+            return None
+        t = t1 + jdiv(hit_distance, ray_length)
+        # (assoc rec ...): the rec handed down by ray-color is {}, so u and v are absent
+        return dict(t=t, p=ray_at(r, t), normal=[1.0, 0.0, 0.0], front_face=True, mat_ptr=o.phase_function, u=None, v=None)
+    raise TypeError(f"not a hittable: {o!r}")
+
+
+# ---- samplers, base.clj:176-197 ----------------------------------------------------------------------------------------
+def random_double(rng, mn, mx): return mn + (mx - mn) * rng()      # base.clj:128
+def random_vec3(rng, mn, mx): return [random_double(rng, mn, mx), random_double(rng, mn, mx), random_double(rng, mn, mx)]
+
+
+def random_in_unit_sphere(rng):
+    """reduce without an initial value: the first draw seeds the accumulator and is never tested; the first LATER draw
+    with |v|^2 >= 1 is returned (base.clj:182-186)."""
+    random_vec3(rng, -1, 1)
+    while True:
+        v = random_vec3(rng, -1, 1)
+        if length_squared(v) >= 1:
+            return v
+
+
+def random_in_unit_disk(rng):  # base.clj:188-194
+    [random_double(rng, -1, 1), random_double(rng, -1, 1), 0]
+    while True:
+        v = [random_double(rng, -1, 1), random_double(rng, -1, 1), 0]
+        if length_squared(v) < 1:
+            return v
+
+
+def random_unit_vector(rng): return unit_vector(random_in_unit_sphere(rng))
+
+
+def reflect(v, n): return vsub(v, vmul(n, 2 * dot(v, n)))     # base.clj:199-200
+
+
+def refract(uv, n, etai_over_etat):  # base.clj:202-209
+    cos_theta = min(dot(neg(uv), n), 1.0)
+    r_out_perp = vmul(vadd(uv, vmul(n, cos_theta)), etai_over_etat)
+    r_out_parallel = vmul(n, -math.sqrt(abs(1.0 - length_squared(r_out_perp))))
+    return vadd(r_out_perp, r_out_parallel)
+
+
+def reflectance(cosine, ref_idx):  # base.clj:215-220
+    r0 = math.pow((1.0 - ref_idx) / (1.0 + ref_idx), 2)
+    return r0 + (1.0 - r0) * math.pow(1 - cosine, 5)
+
+
+# ---- noise.clj, texture.clj ------------------------------------------------------------------------------------------
+def perlin_interp(c, u, v, w):  # noise.clj:21-33
+    uu, vv, ww = (x * x * (3.0 - 2.0 * x) for x in (u, v, w))
+    acc = 0.0
+    for i in (0, 1):
+        for j in (0, 1):
+            for k in (0, 1):
+                weight_v = [u - i, v - j, w - k]
+                acc += ((i * uu + (1 - i) * (1 - uu)) * (j * vv + (1 - j) * (1 - vv)) * (k * ww + (1 - k) * (1 - ww))
+                        * dot(c[i][j][k], weight_v))
+    return acc
+
+
+def noise(perlin, point):  # noise.clj:39-58
+    def smooth(n):
+        value = n - math.floor(n)
+        return value * value * (3 - 2.0 * value)
+    u, v, w = (smooth(n) for n in point)
+    i, j, k = (int(math.floor(n)) for n in point)
+    c = [[[None, None], [None, None]], [[None, None], [None, None]]]
+    for di in (0, 1):
+        for dj in (0, 1):
+            for dk in (0, 1):
+                c[di][dj][dk] = [float(x) for x in perlin.ranvec[int(perlin.perm_x[(i + di) & 255])
+                                                                 | int(perlin.perm_y[(j + dj) & 255])
+                                                                 | int(perlin.perm_z[(k + dk) & 255])]]
+    return perlin_interp(c, u, v, w)
+
+
+def turb(perlin, point, depth):  # noise.clj:59-70
+    acc, weight, temp_p = 0.0, 1.0, list(point)
+    for _ in range(depth):
+        acc = acc + weight * noise(perlin, temp_p)
+        weight = weight * 0.5
+        temp_p = vmul(temp_p, 2)
+    return abs(acc)
+
+
+def clamp(x, mn, mx):  # base.clj:307-310
+    if mn > x:
+        return mn
+    if x > mx:
+        return mx
+    return x
+
+
+def value(tex, u, v, p):
+    if isinstance(tex, T.SolidColor):
+        return [float(c) for c in tex.color_value]
+    if isinstance(tex, T.CheckerTexture):  # texture.clj:25-30
+        sines = 1.0
+        for x in p:
+            sines *= math.sin(10 * x)
+        return value(tex.odd, u, v, p) if sines < 0 else value(tex.even, u, v, p)
+    if isinstance(tex, T.NoiseTexture):  # texture.clj:41-44 (scale is the ^long field)
+        k = 0.5 * (1 + math.sin(tex.scale * p[2] + 10 * turb(tex.perlin_noise, p, 7)))
+        return [k, k, k]
+    if isinstance(tex, T.ImageTexture):  # texture.clj:55-66
+        if tex.data is None:
+            return [0.0, 1.0, 1.0]
+        uu = clamp(u, 0.0, 1.0)
+        vv = 1.0 - clamp(v, 0.0, 1.0)
+        i = 0 if uu != uu else int(uu * tex.width)       # (int NaN) is 0 on the JVM
+        j = 0 if vv != vv else int(vv * tex.height)
+        i = tex.width - 1 if i >= tex.width else i
+        j = tex.height - 1 if j >= tex.height else j
+        return [float(c) * (1.0 / 255.0) for c in tex.data[j][i]]
+    raise TypeError(f"not a texture: {tex!r}")
+
+
+# ---- materials.clj ---------------------------------------------------------------------------------------------------
+def scatter(mat, r_in, rec, rng):
+    """-> dict(ok, attenuation, scattered Ray)."""
+    if isinstance(mat, M.Lambertian):  # :16-23
+        scatter_direction = vadd(rec["normal"], random_unit_vector(rng))
+        return dict(ok=True, scattered=Ray(rec["p"], scatter_direction, r_in.time_),
+                    attenuation=value(mat.albedo, rec["u"], rec["v"], rec["p"]))
+    if isinstance(mat, M.Metal):  # :33-39
+        reflected = reflect(unit_vector(r_in.dir), rec["normal"])
+        scattered = Ray(rec["p"], vadd(reflected, vmul(random_in_unit_sphere(rng), mat.fuzz)), r_in.time_)
+        return dict(ok=dot(scattered.dir, rec["normal"]) > 0, attenuation=[float(c) for c in mat.albedo], scattered=scattered)
+    if isinstance(mat, M.Dielectric):  # :47-61
+        refraction_ratio = (1.0 / mat.ir) if rec["front_face"] else mat.ir
+        unit_direction = unit_vector(r_in.dir)
+        cos_theta = min(dot(neg(unit_direction), rec["normal"]), 1.0)
+        sin_theta = math.sqrt(1.0 - math.pow(cos_theta, 2))
+        cannot_refract = refraction_ratio * sin_theta > 1.0
+        if cannot_refract or reflectance(cos_theta, refraction_ratio) > rng():     # `or`: the draw only when it can refract
+            direction = reflect(unit_direction, rec["normal"])
+        else:
+            direction = refract(unit_direction, rec["normal"], refraction_ratio)
+        return dict(ok=True, attenuation=[1.0, 1.0, 1.0], scattered=Ray(rec["p"], direction, r_in.time_))
+    if isinstance(mat, M.DiffuseLight):  # :69-76: burns a unit vector, never scatters
+        scatter_direction = vadd(rec["normal"], random_unit_vector(rng))
+        return dict(ok=False, scattered=Ray(rec["p"], scatter_direction, r_in.time_),
+                    attenuation=value(mat.emit, rec["u"], rec["v"], rec["p"]))
+    if isinstance(mat, M.Isotropic):  # :87-90
+        return dict(ok=True, scattered=Ray(rec["p"], random_in_unit_sphere(rng), r_in.time_),
+                    attenuation=value(mat.albedo, rec["u"], rec["v"], rec["p"]))
+    raise TypeError(f"not a material: {mat!r}")
+
+
+def emitted(mat, u, v, p):
+    if isinstance(mat, M.DiffuseLight):  # :77-78
+        return value(mat.emit, u, v, p)
+    return [0.0, 0.0, 0.0]
+
+
+# ---- core.clj:19-30, ray.clj:13-26 ------------------------------------------------------------------------------------
+def ray_color(r, background, world, depth, rng, medium_rng):
+    """rng: uniforms for scatter; medium_rng: callable(medium) -> the uniform of that medium's free flight."""
+    if depth <= 0:
+        return [0.0, 0.0, 0.0]
+    rec = _list_hit(world, r, 0.001, INF, medium_rng)
+    if not rec:
+        return [float(c) for c in background]
+    mat = rec["mat_ptr"]
+    em = emitted(mat, rec["u"], rec["v"], rec["p"])
+    s = scatter(mat, r, rec, rng)
+    if s["ok"]:
+        inner = ray_color(s["scattered"], background, world, depth - 1, rng, medium_rng)
+        return [s["attenuation"][q] * inner[q] for q in range(3)]
+    return em
+
+
+def get_ray(cam, s, t, rng):
+    """cam: a dict with the keys of camera.clj:24-33."""
+    d = random_in_unit_disk(rng)
+    x, y, _ = vmul(d, cam["lens_radius"])
+    offset = vadd(vmul(cam["u"], x), vmul(cam["v"], y))
+    direction = vsub(vsub(vadd(vadd(cam["lower_left_corner"], vmul(cam["horizontal"], s)), vmul(cam["vertical"], t)), cam["origin"]), offset)
+    return Ray(vadd(cam["origin"], offset), direction, random_double(rng, cam["time0"], cam["time1"]))
