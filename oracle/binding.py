@@ -53,6 +53,8 @@ def lib():
         L.orc_sampler_scripted.argtypes = [C.c_int32, dp, C.c_int32, dp]
         L.orc_sampler_keyed.argtypes = [C.c_int32, C.c_uint64, C.c_int32, dp]
         L.orc_scatter_scripted.argtypes = [descp, C.c_int32, dp, dp, dp, C.c_int32, dp]
+        L.orc_sample_scripted.argtypes = [descp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), C.c_int32, C.c_int32,
+                                          dp, C.c_int32, dp]
         L.orc_philox.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]
         L.orc_reflectance.argtypes = [C.c_double, C.c_double]
         L.orc_reflectance.restype = C.c_double
@@ -171,6 +173,14 @@ def scatter_scripted(flat, mat, ray7, rec9, script):
                                       _dp(np.asarray(rec9, dtype=np.float64)), _dp(s), len(script), _dp(out))
     return dict(ok=bool(out[0]), attenuation=out[1:4], orig=out[4:7], dir=out[7:10], time=out[10],
                 emitted=out[11:14], used=used)
+
+
+def sample_scripted(flat, cam, params, x, y, script):
+    """One sample of pixel (x, y) with scripted uniforms in the reference's evaluation order -> (rgb, uniforms consumed)."""
+    sc = np.asarray(script, dtype=np.float64)
+    out = np.zeros(3)
+    used = lib().orc_sample_scripted(C.byref(flat.desc), C.byref(cam), C.byref(params), int(x), int(y), _dp(sc), sc.shape[0], _dp(out))
+    return out, used
 
 
 def philox(ctr, key, rounds=0):

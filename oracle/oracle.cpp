@@ -763,6 +763,27 @@ int orc_sample_batch(const rt_scene_desc* d, const rt_camera* cam, const rt_para
   return 0;
 }
 
+// One sample of pixel (x, y) with SCRIPTED uniforms consumed in the reference's evaluation order (core.clj:96-105: the
+// two jitters, get-ray's disk draws and its time, then ray-color's draws bounce by bounce, a medium's free-flight draw
+// where the scan reaches it). out_rgb3 = the sample's radiance; returns the uniforms consumed, -1 on overrun.
+int orc_sample_scripted(const rt_scene_desc* d, const rt_camera* cam, const rt_params* prm, int32_t x, int32_t y,
+                        const double* script, int32_t n, double* out_rgb3) {
+  Scene s{d};
+  Counters cnt;
+  Rng rng;
+  rng.script = script;
+  rng.script_n = n;
+  double jx, jy;
+  rng.camera(jx, jy);
+  double su = (x + jx) / (double)(prm->width - 1);
+  double sv = (y + jy) / (double)(prm->height - 1);
+  Ray r = get_ray(*cam, su, sv, rng);
+  V3 bg{prm->background[0], prm->background[1], prm->background[2]};
+  V3 c = ray_color(s, r, bg, prm->max_depth, rng, 0, cnt);
+  out_rgb3[0] = c.x; out_rgb3[1] = c.y; out_rgb3[2] = c.z;
+  return rng.script_overrun ? -1 : rng.script_pos;
+}
+
 // The rays one (pixel, sample) path hands to `hit`, in order: out7[7*k..] = orig dir time (FP64).
 // Returns the number of rays (at most max_rays are written).
 int orc_path_rays(const rt_scene_desc* d, const rt_camera* cam, const rt_params* prm, int32_t px,

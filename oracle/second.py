@@ -368,3 +368,45 @@ def get_ray(cam, s, t, rng):
     offset = vadd(vmul(cam["u"], x), vmul(cam["v"], y))
     direction = vsub(vsub(vadd(vadd(cam["lower_left_corner"], vmul(cam["horizontal"], s)), vmul(cam["vertical"], t)), cam["origin"]), offset)
     return Ray(vadd(cam["origin"], offset), direction, random_double(rng, cam["time0"], cam["time1"]))
+
+
+def camera(lookfrom, lookat, vup, vfov, aspect_ratio, aperture, focus_dist, time0, time1):
+    """camera.clj:7-32 -> the camera map (a dict with its keys)."""
+    theta = math.radians(vfov)
+    h = math.tan(theta * 0.5)
+    viewport_height = h * 2.0
+    viewport_width = aspect_ratio * viewport_height
+    w = unit_vector(vsub(list(lookfrom), list(lookat)))
+    vup = list(vup)
+    u = unit_vector([vup[1] * w[2] - vup[2] * w[1], vup[2] * w[0] - vup[0] * w[2], vup[0] * w[1] - vup[1] * w[0]])
+    v = [w[1] * u[2] - w[2] * u[1], w[2] * u[0] - w[0] * u[2], w[0] * u[1] - w[1] * u[0]]
+    origin = [float(c) for c in lookfrom]
+    horizontal = vmul(u, focus_dist * viewport_width)
+    vertical = vmul(v, focus_dist * viewport_height)
+    lower_left_corner = vsub(vsub(vsub(origin, vd(horizontal, 2)), vd(vertical, 2)), vmul(w, focus_dist))
+    return dict(origin=origin, lower_left_corner=lower_left_corner, horizontal=horizontal, vertical=vertical, u=u, v=v, w=w,
+                lens_radius=aperture / 2, time0=time0, time1=time1)
+
+
+def sample(cam, image_width, image_height, x, y, background, world, max_depth, rng):
+    """core.clj:96-105: one sample of pixel (x, y); every uniform, the media's included, comes from `rng` in the
+    order the reference evaluates them."""
+    s = (x + rng()) / (image_width - 1)
+    t = (y + rng()) / (image_height - 1)
+    return ray_color(get_ray(cam, s, t, rng), background, world, max_depth, rng, lambda medium: rng())
+
+
+def pack_pixel(acc, samples_per_pixel):
+    """core.clj:106-108,118,121-122: scale, sqrt, clamp to [0, 0.999], the ^float destructuring, then
+    java.awt.Color(float, float, float).getRGB(): each channel (int)(c * 255 + 0.5) with c * 255 a float product,
+    (int) NaN = 0, alpha 255."""
+    import numpy as np
+    scale = 1.0 / samples_per_pixel
+    out = []
+    for x in acc:
+        x = x * scale
+        c = clamp(math.sqrt(x) if x >= 0 else float("nan"), 0.0, 0.999)
+        f = np.float32(c)
+        scaled = float(np.float32(f * np.float32(255.0))) + 0.5
+        out.append(0 if scaled != scaled else int(scaled) & 0xFF)
+    return 0xFF000000 | (out[0] << 16) | (out[1] << 8) | out[2]

@@ -198,3 +198,48 @@ def test_samplers_agree_draw_for_draw(which, fn):
         assert used == draws.pos
         for q in range(3):
             assert _close(got[q], want[q])
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_whole_samples_agree_with_scripted_draws(name):
+    """core.clj:96-105 end to end — the two jitters, get-ray (lens disk, shutter time), ray-color to its depth limit
+    with media, scatter and textures on the way — on both sides with ONE scripted sequence of uniforms consumed in
+    the reference's evaluation order: the radiance of the sample and the number of uniforms consumed must agree, and
+    the camera map of camera.clj must be the one the host mirror hands the library."""
+    from raytracing_amd import abi
+    from raytracing_amd.core import build_camera
+    cfg, world, f, flat = _world(name)
+    W = H = 40
+    cam_abi = build_camera(cfg, 1.0)
+    cam = S.camera(cfg["lookfrom"], cfg["lookat"], (0.0, 1.0, 0.0), cfg["vfov"], 1.0, cfg["aperture"], 10.0, 0.0, 1.0)
+    for key, field in (("origin", cam_abi.origin), ("lower_left_corner", cam_abi.lower_left_corner), ("horizontal", cam_abi.horizontal),
+                       ("vertical", cam_abi.vertical), ("u", cam_abi.u), ("v", cam_abi.v), ("w", cam_abi.w)):
+        for q in range(3):
+            assert _close(cam[key][q], field[q], 1.0), (name, key)
+    assert cam["lens_radius"] == cam_abi.lens_radius and (cam["time0"], cam["time1"]) == (cam_abi.time0, cam_abi.time1)
+    params = abi.make_params(W, H, 1, 50, cfg["background"], seed=1)
+    rng = np.random.default_rng(23)
+    n = 12 if name in ("final-scene", "random-scene") else 40
+    lit = 0
+    for _ in range(n):
+        x, y = int(rng.integers(0, W)), int(rng.integers(0, H))
+        script = [float(v) for v in rng.random(4000)]
+        draws = _Scripted(script)
+        want = S.sample(cam, W, H, x, y, cfg["background"], world, 50, draws)
+        got, used = ob.sample_scripted(flat, cam_abi, params, x, y, script)
+        assert used == draws.pos, (name, x, y, used, draws.pos)
+        for q in range(3):
+            assert _close(got[q], want[q], 1e-6), (name, x, y, got, want)
+        lit += any(c > 0 for c in want)
+    assert lit > 0, name
+
+
+def test_pixel_packing_agrees():
+    rng = np.random.default_rng(31)
+    cases = [(0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (0.25, 1.5, float("nan")), (1e-9, 0.998001, 0.998002), (4.0, 0.5, 0.0625), (-0.0, 0.0, 3e38)]
+    cases += [tuple(float(v) for v in rng.uniform(0, 1.3, 3)) for _ in range(300)]
+    for spp in (1, 7, 1000):
+        for c in cases:
+            acc = [v * spp for v in c]
+            assert ob.pack_pixel(acc[0], acc[1], acc[2], spp) == S.pack_pixel(acc, spp), (c, spp)
+    assert S.pack_pixel([0.25, 1.5, float("nan")], 1) == 0xFF80FF00      # the known answer of the survey's K13
