@@ -67,6 +67,7 @@
 (def ^:private rt-multi-scene-destroy (down "rt_multi_scene_destroy" (fd-void ADDR)))
 (def ^:private rt-multi-render (down "rt_multi_render" (fd I32 ADDR ADDR ADDR ADDR I32 ADDR ADDR ADDR)))
 (def ^:private rt-image-decode-jpeg (down "rt_image_decode_jpeg" (fd I32 ADDR I64 ADDR ADDR ADDR I64)))
+(def ^:private rt-image-decode (down "rt_image_decode" (fd I32 ADDR I64 ADDR ADDR ADDR I64)))
 
 (defn- call [^MethodHandle h & args]
   (.invokeWithArguments h ^java.util.List (vec args)))
@@ -214,18 +215,28 @@
               (finally (call rt-multi-scene-destroy ms))))
           (finally (call rt-multi-shutdown m)))))))
 
-(defn decode-jpeg
-  "(image-texture url)'s decode step by the library (texture.clj:68-81): the bytes of a JPEG file ->
-  {:width w :height h :rgb8 byte[]} (top row first, R G B)."
-  [^bytes file-bytes]
+(defn- decode-with
+  [^MethodHandle entry ^bytes file-bytes]
   (with-open [arena (Arena/ofConfined)]
     (let [src (.allocateFrom arena ValueLayout/JAVA_BYTE file-bytes)
           pw (.allocate arena I32)
           ph (.allocate arena I32)
           n (long (alength file-bytes))]
-      (check! (call rt-image-decode-jpeg src n pw ph MemorySegment/NULL (long 0)))
+      (check! (call entry src n pw ph MemorySegment/NULL (long 0)))
       (let [w (.get pw ^java.lang.foreign.ValueLayout$OfInt I32 0)
             h (.get ph ^java.lang.foreign.ValueLayout$OfInt I32 0)
             out (.allocate arena (long (* 3 w h)) 1)]
-        (check! (call rt-image-decode-jpeg src n pw ph out (long (* 3 w h))))
+        (check! (call entry src n pw ph out (long (* 3 w h))))
         {:width w :height h :rgb8 (.toArray out ValueLayout/JAVA_BYTE)}))))
+
+(defn decode-jpeg
+  "(image-texture url)'s decode step by the library (texture.clj:68-81): the bytes of a JPEG file ->
+  {:width w :height h :rgb8 byte[]} (top row first, R G B)."
+  [^bytes file-bytes]
+  (decode-with rt-image-decode-jpeg file-bytes))
+
+(defn decode-image
+  "The same for a JPEG or a PNG file, told apart by the first bytes as ImageIO/read tells them apart
+  (texture.clj:72)."
+  [^bytes file-bytes]
+  (decode-with rt-image-decode file-bytes))

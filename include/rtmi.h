@@ -373,6 +373,26 @@ int rt_image_decode_jpeg(const uint8_t* bytes, uint64_t n_bytes, int32_t* width,
                          uint8_t* rgb8, uint64_t capacity);
 
 /*
+ * The same call for a PNG file (texture.clj:72: ImageIO/read takes either): every colour type and bit
+ * depth of ISO/IEC 15948, Adam7 interlacing, chunk CRCs and the Adler-32 of the image data checked.
+ * An 8-bit RGB file gives exactly the bytes the reference's raster read gives (texture.clj:73-77). The
+ * reference's read assumes three bytes per pixel, so it scrambles grey, palette and RGBA rasters and
+ * throws on 16-bit ones; here those become what the file shows: grey replicated to R = G = B (1, 2
+ * and 4 bits scaled to 0..255), palette entries looked up, 16-bit samples rounded to 8 bits, alpha
+ * and tRNS dropped without compositing. Same arguments and errors as rt_image_decode_jpeg;
+ * RT_ERR_UNSUPPORTED: more than 2^28 pixels.
+ */
+int rt_image_decode_png(const uint8_t* bytes, uint64_t n_bytes, int32_t* width, int32_t* height,
+                        uint8_t* rgb8, uint64_t capacity);
+
+/*
+ * ImageIO/read itself (texture.clj:72): picks the decoder by the file's first bytes, not by its name
+ * (resources/map2.png is a JPEG and loads as one). RT_ERR_UNSUPPORTED: neither a JPEG nor a PNG file.
+ */
+int rt_image_decode(const uint8_t* bytes, uint64_t n_bytes, int32_t* width, int32_t* height,
+                    uint8_t* rgb8, uint64_t capacity);
+
+/*
  * Several GPUs behind one handle, for a caller that is ONE process (the JVM): what replaces the
  * reference's fan-out of a frame over one thread per image row and its latch (core.clj:44-48,
  * 95,109-128). rt_multi_init binds one context per listed device; rt_multi_scene_create uploads

@@ -49,6 +49,22 @@ def write_ppm(path: str, argb: np.ndarray) -> None:
         f.write(rgb.tobytes())
 
 
+def write_png(path: str, argb: np.ndarray) -> None:
+    """The same frame as an 8-bit RGB PNG (one zlib stream, filter 0 on every row), top row first."""
+    import struct
+    import zlib
+    H, W = argb.shape
+    flipped = argb[::-1]
+    rgb = np.stack([(flipped >> 16) & 255, (flipped >> 8) & 255, flipped & 255], axis=-1).astype(np.uint8)
+    raw = np.concatenate([np.zeros((H, 1), np.uint8), rgb.reshape(H, W * 3)], axis=1).tobytes()
+
+    def chunk(kind: bytes, body: bytes) -> bytes:
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 def main(samples: int = 30, scene: str = "final-scene", image_width: int = 200, aspect_ratio: float = 1.0,
          max_depth: int = 50, scene_seed: int = 1, seed: int = 0x5EED0001, device: int = 0,
          output: Optional[str] = None, devices: Optional[Sequence[int]] = None, split: str = "tile"):
@@ -79,7 +95,7 @@ def main(samples: int = 30, scene: str = "final-scene", image_width: int = 200, 
             sc.close()
             ctx.close()
     if output:
-        write_ppm(output, argb)
+        (write_png if output.lower().endswith(".png") else write_ppm)(output, argb)
     return argb, stats
 
 
@@ -94,7 +110,7 @@ if __name__ == "__main__":  # python -m raytracing_amd.core --samples 10 [--scen
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--gpus", default="0", help="device ids, comma-separated; more than one renders through rt_multi_*")
     ap.add_argument("--split", default="tile", choices=["tile", "sample"])
-    ap.add_argument("--output", default=None, help="write the frame as a binary PPM")
+    ap.add_argument("--output", default=None, help="write the frame to this file: a PNG if the name ends in .png, else a binary PPM")
     a = ap.parse_args()
     ids = [int(v) for v in a.gpus.split(",")]
     _, st = main(a.samples, a.scene, a.width, a.aspect, a.depth, devices=ids, split=a.split, output=a.output)

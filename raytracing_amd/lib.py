@@ -19,7 +19,7 @@ EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version", "rt_scen
            "rt_scene_create_with", "rt_scene_bvh_digest", "rt_scene_get_variants", "rt_hit_batch_variant", "rt_scatter_batch",
            "rt_render_device_noalloc", "rt_get_device_info", "rt_multi_init", "rt_multi_shutdown",
            "rt_multi_device_count", "rt_multi_selftest_rccl", "rt_multi_last_error", "rt_multi_scene_create", "rt_multi_scene_destroy",
-           "rt_multi_render", "rt_image_decode_jpeg"]
+           "rt_multi_render", "rt_image_decode_jpeg", "rt_image_decode_png", "rt_image_decode"]
 
 _LIB = None
 
@@ -60,7 +60,8 @@ def load():
     L.rt_hit_batch_variant.argtypes = [vp, vp, C.c_int32, C.c_int32, fp, fp, fp, C.c_float, C.c_float, fp,
                                        C.POINTER(abi.rt_hit)]
     L.rt_scatter_batch.argtypes = [vp, vp, C.c_uint64, C.c_int32, fp, fp, fp, ip, ip, ip, C.POINTER(abi.rt_scatter)]
-    L.rt_image_decode_jpeg.argtypes = [C.c_char_p, C.c_uint64, ip, ip, vp, C.c_uint64]
+    for f in (L.rt_image_decode_jpeg, L.rt_image_decode_png, L.rt_image_decode):
+        f.argtypes = [C.c_char_p, C.c_uint64, ip, ip, vp, C.c_uint64]
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_scene_destroy.restype = None
     L.rt_get_device_info.argtypes = [vp, C.POINTER(abi.rt_device_info)]
@@ -161,19 +162,34 @@ class Context:
         _check(self._L.rt_tonemap_device(self._h, d_rgb_sum_ptr, n_pixels, spp_total, d_argb_ptr, stream or None))
 
 
-def decode_jpeg(data: bytes) -> np.ndarray:
-    """(image-texture url)'s decode step, texture.clj:68-81, through the library: the bytes of a JPEG
-    file -> (h, w, 3) uint8, top row first, R G B. Host code: needs no GPU."""
+def _decode(entry: str, data: bytes) -> np.ndarray:
     L = load()
+    f = getattr(L, entry)
     w, h = C.c_int32(0), C.c_int32(0)
-    rc = L.rt_image_decode_jpeg(data, len(data), C.byref(w), C.byref(h), None, 0)
+    rc = f(data, len(data), C.byref(w), C.byref(h), None, 0)
     if rc != 0:
         raise RtError(rc, L.rt_last_error().decode())
     out = np.empty((h.value, w.value, 3), dtype=np.uint8)
-    rc = L.rt_image_decode_jpeg(data, len(data), C.byref(w), C.byref(h), out.ctypes.data, out.nbytes)
+    rc = f(data, len(data), C.byref(w), C.byref(h), out.ctypes.data, out.nbytes)
     if rc != 0:
         raise RtError(rc, L.rt_last_error().decode())
     return out
+
+
+def decode_jpeg(data: bytes) -> np.ndarray:
+    """(image-texture url)'s decode step, texture.clj:68-81, through the library: the bytes of a JPEG
+    file -> (h, w, 3) uint8, top row first, R G B. Host code: needs no GPU."""
+    return _decode("rt_image_decode_jpeg", data)
+
+
+def decode_png(data: bytes) -> np.ndarray:
+    """The same for the bytes of a PNG file (rt_image_decode_png)."""
+    return _decode("rt_image_decode_png", data)
+
+
+def decode_image(data: bytes) -> np.ndarray:
+    """ImageIO/read of texture.clj:72: JPEG or PNG, told apart by the first bytes (rt_image_decode)."""
+    return _decode("rt_image_decode", data)
 
 
 class MultiContext:

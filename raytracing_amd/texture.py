@@ -86,17 +86,15 @@ ASSET_DIR = os.path.join(os.path.dirname(__file__), "assets")
 
 def load_rgb8(path: str) -> np.ndarray:
     """Decode an image file to (h, w, 3) uint8, as ImageIO/read does for the reference (texture.clj:72).
-    JPEG files (by their first bytes, whatever the name: resources/map2.png is one) are decoded by the
-    library's own decoder, rt_image_decode_jpeg; `.npz` files (key 'rgb8') hold decoded arrays."""
+    JPEG and PNG files (told apart by their first bytes, whatever the name: resources/map2.png is a JPEG)
+    are decoded by the library's own decoders, rt_image_decode; `.npz` files (key 'rgb8') hold decoded arrays."""
     if path.endswith(".npz"):
         with np.load(path) as z:
             return np.ascontiguousarray(z["rgb8"], dtype=np.uint8)
     with open(path, "rb") as f:
         data = f.read()
-    if data[:2] != b"\xff\xd8":
-        raise ValueError(f"{path}: only JPEG files (and .npz arrays) are read")
     from . import lib
-    return lib.decode_jpeg(data)
+    return lib.decode_image(data)
 
 
 def image_texture(source=None) -> ImageTexture:  # texture.clj:68-81

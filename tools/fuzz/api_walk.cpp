@@ -3,7 +3,7 @@
 // library wants its runtime loaded before the interpreter. Needs a GPU.
 //   hipcc -O1 -g -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -fno-gpu-rdc -Xarch_host -fsanitize=address \
 //     -Xarch_host -fsanitize=undefined -shared -o librtmi_asan.so raytracing_amd/csrc/{rt_api,rt_kernels,rt_bvh,rt_multi}.hip \
-//     raytracing_amd/csrc/rt_jpeg.cpp -ldl -lpthread
+//     raytracing_amd/csrc/rt_jpeg.cpp raytracing_amd/csrc/rt_png.cpp -ldl -lpthread
 //   hipcc -O1 -g -std=c++17 --offload-arch=gfx950 -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined \
 //     tools/fuzz/api_walk.cpp -L. -lrtmi_asan -Wl,-rpath,'$ORIGIN' -o api_walk
 //   ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 ./api_walk <scene files written by rt_scene_write> -- <JPEG files>

@@ -4,6 +4,7 @@
 #   scene_fuzz       mutated scene files against rt_scene_create_from_memory (+ a render and queries for some)
 #   api_walk         every entry point of include/rtmi.h with ordinary arguments
 #   jpeg_fuzz        mutated JPEG files against rt_image_decode_jpeg (host only: runs without a GPU)
+#   png_fuzz         mutated PNG files (chunk bodies edited, CRCs made right again) against rt_image_decode_png (host only)
 # and writes the reference's worlds as scene files beside them. Usage: bash tools/fuzz/build.sh
 # Then, on the GPU box (gpurun): cd gpurun_tmp && ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 ./api_walk *.rtscn -- *.jpg
 set -e
@@ -11,12 +12,13 @@ cd "$(dirname "$0")/../.."
 mkdir -p gpurun_tmp
 SAN="-Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined"
 (cd raytracing_amd/csrc && /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -fno-gpu-rdc -w $SAN \
-   -shared -o ../../gpurun_tmp/librtmi_asan.so rt_api.hip rt_kernels.hip rt_bvh.hip rt_multi.hip rt_jpeg.cpp -ldl -lpthread)
+   -shared -o ../../gpurun_tmp/librtmi_asan.so rt_api.hip rt_kernels.hip rt_bvh.hip rt_multi.hip rt_jpeg.cpp rt_png.cpp -ldl -lpthread)
 /opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -fsanitize=address,undefined tools/fuzz/scene_fuzz.cpp -Lgpurun_tmp -lrtmi_asan \
    -Wl,-rpath,'$ORIGIN' -o gpurun_tmp/scene_fuzz
 /opt/rocm/bin/hipcc -O1 -g -std=c++17 --offload-arch=gfx950 -w $SAN tools/fuzz/api_walk.cpp -Lgpurun_tmp -lrtmi_asan \
    -Wl,-rpath,'$ORIGIN' -o gpurun_tmp/api_walk
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined tools/fuzz/jpeg_fuzz.cpp raytracing_amd/csrc/rt_jpeg.cpp -o gpurun_tmp/jpeg_fuzz
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined tools/fuzz/png_fuzz.cpp raytracing_amd/csrc/rt_png.cpp raytracing_amd/csrc/rt_jpeg.cpp -o gpurun_tmp/png_fuzz
 python3 - <<'PY'
 import sys
 sys.path.insert(0, ".")
