@@ -6,7 +6,7 @@
 //     raytracing_amd/csrc/rt_jpeg.cpp raytracing_amd/csrc/rt_png.cpp -ldl -lpthread
 //   hipcc -O1 -g -std=c++17 --offload-arch=gfx950 -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined \
 //     tools/fuzz/api_walk.cpp -L. -lrtmi_asan -Wl,-rpath,'$ORIGIN' -o api_walk
-//   ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 ./api_walk <scene files written by rt_scene_write> -- <JPEG files>
+//   ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 ./api_walk <scene files written by rt_scene_write> -- <JPEG and PNG files>
 #include <hip/hip_runtime.h>
 #include <unistd.h>
 #include <cstdint>
@@ -214,10 +214,14 @@ int main(int argc, char** argv) {
   for (++a; a < argc; ++a) {
     const std::vector<uint8_t> file = slurp(argv[a]);
     int32_t w = 0, h = 0;
-    OK(rt_image_decode_jpeg(file.data(), file.size(), &w, &h, nullptr, 0));
-    std::vector<uint8_t> rgb((size_t)w * (size_t)h * 3);
-    OK(rt_image_decode_jpeg(file.data(), file.size(), &w, &h, rgb.data(), rgb.size()));
-    printf("%s: %d x %d\n", argv[a], w, h);
+    // by content (JPEG or PNG), then once more through the decoder the first bytes name
+    OK(rt_image_decode(file.data(), file.size(), &w, &h, nullptr, 0));
+    std::vector<uint8_t> rgb((size_t)w * (size_t)h * 3), again(rgb.size());
+    OK(rt_image_decode(file.data(), file.size(), &w, &h, rgb.data(), rgb.size()));
+    const bool png = file.size() > 1 && file[0] == 0x89;
+    OK((png ? rt_image_decode_png : rt_image_decode_jpeg)(file.data(), file.size(), &w, &h, again.data(), again.size()));
+    if (rgb != again) { printf("%s: the two entry points disagree\n", argv[a]); return 1; }
+    printf("%s: %d x %d (%s)\n", argv[a], w, h, png ? "PNG" : "JPEG");
   }
   // what must be refused is refused
   {

@@ -6,7 +6,7 @@
 #   jpeg_fuzz        mutated JPEG files against rt_image_decode_jpeg (host only: runs without a GPU)
 #   png_fuzz         mutated PNG files (chunk bodies edited, CRCs made right again) against rt_image_decode_png (host only)
 # and writes the reference's worlds as scene files beside them. Usage: bash tools/fuzz/build.sh
-# Then, on the GPU box (gpurun): cd gpurun_tmp && ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 ./api_walk *.rtscn -- *.jpg
+# Then, on the GPU box (gpurun): cd gpurun_tmp && ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 ./api_walk *.rtscn -- *.jpg *.png
 set -e
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_tmp
@@ -29,4 +29,13 @@ for name in ("cornell-box", "cornell-smoke", "final-scene", "two-perlin-spheres"
     open(f"gpurun_tmp/{name}.rtscn", "wb").write(scenefile.dumps(flat))
 PY
 cp raytracing_amd/assets/earthmap.jpg raytracing_amd/assets/stones.jpg raytracing_amd/assets/map2.png gpurun_tmp/
+python3 - <<'PY'
+import numpy as np
+from PIL import Image
+with np.load("raytracing_amd/assets/stones_rgb8.npz") as z:
+    rgb = z["rgb8"]
+Image.fromarray(rgb).save("gpurun_tmp/stones_rgb.png")
+Image.fromarray(rgb).quantize(200).save("gpurun_tmp/stones_palette.png")
+Image.fromarray(rgb).convert("LA").save("gpurun_tmp/stones_grey_alpha.png")
+PY
 echo built gpurun_tmp/
