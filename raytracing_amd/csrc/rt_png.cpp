@@ -58,25 +58,41 @@ uint32_t crc32(const uint8_t* p, size_t n) {
 struct Bits {
   const uint8_t* p;
   size_t n, pos = 0;
-  uint32_t hold = 0;
-  int have = 0;
-  uint32_t take(int k) {  // k <= 16 bits, least significant first
-    while (have < k) {
-      if (pos >= n) bad("the compressed image data ends early");
-      hold |= (uint32_t)p[pos++] << have;
+  uint64_t hold = 0;  // bits not yet used, the next one lowest; beyond the end of the data the buffer reads as zeros
+  int have = 0;       // how many of them are real
+  void refill() {
+    while (have <= 56 && pos < n) {
+      hold |= (uint64_t)p[pos++] << have;
       have += 8;
     }
-    const uint32_t v = hold & ((1u << k) - 1u);
+  }
+  uint32_t peek(int k) const { return (uint32_t)(hold & ((1ull << k) - 1ull)); }
+  void drop(int k) {
+    if (k > have) bad("the compressed image data ends early");
     hold >>= k;
     have -= k;
+  }
+  uint32_t take(int k) {  // k <= 16 bits, least significant first
+    refill();
+    const uint32_t v = peek(k);
+    drop(k);
     return v;
   }
-  void to_byte() { hold = 0; have = 0; }  // the bits left in the current byte are dropped
+  void to_byte() {  // the rest of the current byte is dropped, whole bytes read ahead are handed back
+    pos -= (size_t)(have >> 3);
+    hold = 0;
+    have = 0;
+  }
 };
+
+constexpr int FAST = 10;
 
 struct Code {  // a canonical Huffman code: how many codes of each length, symbols in code order
   uint16_t count[16];
   uint16_t symbol[288];
+  // codes of up to FAST bits resolved by one lookup on the next FAST bits of the stream: symbol << 4 | length; 0 = a
+  // longer code, or none
+  uint16_t fast[1 << FAST];
   // false: more codes of some length than a prefix code has room for
   bool build(const uint8_t* lengths, int n) {
     memset(count, 0, sizeof count);
@@ -87,17 +103,38 @@ struct Code {  // a canonical Huffman code: how many codes of each length, symbo
       left -= count[l];
       if (left < 0) return false;
     }
-    uint16_t offs[16];
+    uint16_t offs[16], next[16];
     offs[1] = 0;
     for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
     for (int i = 0; i < n; ++i)
       if (lengths[i]) symbol[offs[lengths[i]]++] = (uint16_t)i;
+    // the codes themselves (RFC 1951, 3.2.2), bit-reversed because the stream delivers a code's first bit lowest
+    memset(fast, 0, sizeof fast);
+    uint32_t code = 0;
+    for (int l = 1; l < 16; ++l) {
+      code = (code + (l > 1 ? count[l - 1] : 0u)) << 1;
+      next[l] = (uint16_t)code;
+    }
+    for (int i = 0; i < n; ++i) {
+      const int l = lengths[i];
+      if (l == 0 || l > FAST) continue;  // (longer codes are found bit by bit from the counts)
+      uint32_t c = next[l]++, rev = 0;
+      for (int k = 0; k < l; ++k) rev |= ((c >> k) & 1u) << (l - 1 - k);
+      for (uint32_t hi = 0; hi < (1u << (FAST - l)); ++hi) fast[rev | (hi << l)] = (uint16_t)((i << 4) | l);
+    }
     return true;
   }
   int decode(Bits& b) const {
+    b.refill();
+    const uint16_t e = fast[b.peek(FAST)];
+    if (e) {
+      b.drop(e & 15);
+      return e >> 4;
+    }
     int code = 0, first = 0, index = 0;
     for (int l = 1; l < 16; ++l) {
-      code |= (int)b.take(1);
+      code |= (int)b.peek(1);
+      b.drop(1);
       const int c = count[l];
       if (code - c < first) return symbol[index + (code - first)];
       index += c;
@@ -120,8 +157,9 @@ void inflate_exact(const uint8_t* z, size_t n, std::vector<uint8_t>& out, size_t
   if ((z[0] & 0x0F) != 8 || (z[0] >> 4) > 7 || (((unsigned)z[0] << 8) | z[1]) % 31 != 0) bad("the image data is not a zlib stream");
   if (z[1] & 0x20) bad("a zlib stream with a preset dictionary");
   Bits b{z + 2, n - 2};
-  out.clear();
-  out.reserve(want);
+  out.assign(want, 0);
+  uint8_t* const o = out.data();
+  size_t at = 0;  // bytes written
   Code lit, dist;
   for (bool last = false; !last;) {
     last = b.take(1) != 0;
@@ -133,8 +171,9 @@ void inflate_exact(const uint8_t* z, size_t n, std::vector<uint8_t>& out, size_t
       b.pos += 4;
       if ((len ^ nlen) != 0xFFFFu) bad("a stored block whose length check fails");
       if (b.n - b.pos < len) bad("the compressed image data ends early");
-      if (want - out.size() < len) bad("more image data than the header announces");
-      out.insert(out.end(), b.p + b.pos, b.p + b.pos + len);
+      if (want - at < len) bad("more image data than the header announces");
+      memcpy(o + at, b.p + b.pos, len);
+      at += len;
       b.pos += len;
       continue;
     }
@@ -180,8 +219,8 @@ void inflate_exact(const uint8_t* z, size_t n, std::vector<uint8_t>& out, size_t
     for (;;) {
       const int s = lit.decode(b);
       if (s < 256) {
-        if (out.size() >= want) bad("more image data than the header announces");
-        out.push_back((uint8_t)s);
+        if (at >= want) bad("more image data than the header announces");
+        o[at++] = (uint8_t)s;
         continue;
       }
       if (s == 256) break;
@@ -190,13 +229,14 @@ void inflate_exact(const uint8_t* z, size_t n, std::vector<uint8_t>& out, size_t
       const int ds = dist.decode(b);
       if (ds > 29) bad("a distance code that does not exist");
       const size_t d = DIST_BASE[ds] + b.take(DIST_EXTRA[ds]);
-      if (d > out.size()) bad("a distance that reaches before the start of the data");
-      if (want - out.size() < len) bad("more image data than the header announces");
-      size_t from = out.size() - d;
-      for (size_t k = 0; k < len; ++k) out.push_back(out[from + k]);  // may overlap what it writes
+      if (d > at) bad("a distance that reaches before the start of the data");
+      if (want - at < len) bad("more image data than the header announces");
+      const uint8_t* from = o + at - d;
+      for (size_t k = 0; k < len; ++k) o[at + k] = from[k];  // may overlap what it writes
+      at += len;
     }
   }
-  if (out.size() != want) bad("less image data than the header announces");
+  if (at != want) bad("less image data than the header announces");
   b.to_byte();
   if (b.n - b.pos < 4) bad("the compressed image data ends early");
   uint32_t s1 = 1, s2 = 0;  // Adler-32 of what came out

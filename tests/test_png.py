@@ -148,6 +148,16 @@ def test_each_row_filter_and_each_kind_of_deflate_block(filt, level):
         assert np.array_equal(lib.decode_png(data), expected_rgb(s, ctype, depth))
 
 
+def test_codes_longer_than_the_lookup_table():
+    """Sample values with a geometric distribution: the rare ones get Huffman codes of 11 to 15 bits, which the decoder
+    finds bit by bit from the code-length counts instead of by its ten-bit table."""
+    rng = np.random.default_rng(77)
+    s = np.minimum(rng.geometric(0.35, (300, 400, 1)) - 1, 255).astype(np.int64)
+    data = make_png(s, 0, 8, filters=(0,), level=9)
+    assert np.array_equal(lib.decode_png(data), expected_rgb(s, 0, 8))
+    assert np.array_equal(lib.decode_png(data), np.asarray(Image.open(io.BytesIO(data)).convert("RGB")))
+
+
 @pytest.mark.parametrize("mode,kw", [("RGB", dict()), ("RGB", dict(optimize=True)), ("RGB", dict(compress_level=0)),
                                      ("RGBA", dict()), ("L", dict()), ("LA", dict()), ("P", dict()), ("1", dict()),
                                      ("RGB", dict(compress_level=1))])
