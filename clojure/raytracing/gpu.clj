@@ -236,7 +236,7 @@
   (decode-with rt-image-decode-jpeg file-bytes))
 
 (defn decode-image
-  "The same for a JPEG or a PNG file, told apart by the first bytes as ImageIO/read tells them apart
+  "The same for a JPEG, PNG, GIF or BMP file, told apart by the first bytes as ImageIO/read tells them apart
   (texture.clj:72)."
   [^bytes file-bytes]
   (decode-with rt-image-decode file-bytes))

@@ -386,8 +386,23 @@ int rt_image_decode_png(const uint8_t* bytes, uint64_t n_bytes, int32_t* width, 
                         uint8_t* rgb8, uint64_t capacity);
 
 /*
+ * The other two formats ImageIO/read (texture.clj:72) reads out of the box. GIF: the first image of the
+ * file at its own size (what ImageIO/read returns), through its local or the global colour table,
+ * interlaced or not, transparency ignored. BMP: 1-, 4-, 8-bit palette, 16-, 24-, 32-bit, bottom-up or
+ * top-down, uncompressed or bit fields; RT_ERR_UNSUPPORTED for run-length coded files. A 24-bit BMP
+ * gives exactly the bytes the reference's raster read gives (texture.clj:73-77); the palette and
+ * other depths, which that read scrambles or throws on, become the picture the file holds. Same
+ * arguments and errors as rt_image_decode_jpeg; RT_ERR_UNSUPPORTED: more than 2^28 pixels.
+ */
+int rt_image_decode_gif(const uint8_t* bytes, uint64_t n_bytes, int32_t* width, int32_t* height,
+                        uint8_t* rgb8, uint64_t capacity);
+int rt_image_decode_bmp(const uint8_t* bytes, uint64_t n_bytes, int32_t* width, int32_t* height,
+                        uint8_t* rgb8, uint64_t capacity);
+
+/*
  * ImageIO/read itself (texture.clj:72): picks the decoder by the file's first bytes, not by its name
- * (resources/map2.png is a JPEG and loads as one). RT_ERR_UNSUPPORTED: neither a JPEG nor a PNG file.
+ * (resources/map2.png is a JPEG and loads as one). RT_ERR_UNSUPPORTED: not a JPEG, PNG, GIF or BMP
+ * file (WBMP and TIFF are not read).
  */
 int rt_image_decode(const uint8_t* bytes, uint64_t n_bytes, int32_t* width, int32_t* height,
                     uint8_t* rgb8, uint64_t capacity);

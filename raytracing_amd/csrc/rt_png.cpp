@@ -1,10 +1,10 @@
-// rt_png.cpp — a PNG decoder behind the C ABI, and the call that tells the two image formats apart
+// rt_png.cpp — a PNG decoder behind the C ABI, and the call that tells the image formats apart
 // (host code, no dependency).
 //
 // The reference's (image-texture url) hands its URL to javax.imageio.ImageIO/read (texture.clj:72), which
 // picks the reader by the file's first bytes, not its name (that is why resources/map2.png, a JPEG, loads).
-// rt_image_decode does the same for the two formats this library reads; rt_image_decode_png is the PNG
-// side: ISO/IEC 15948 with the inflate of RFC 1950 / 1951 written out here. Every colour type and bit
+// rt_image_decode does the same for the formats this library reads (JPEG, PNG, and GIF and BMP from
+// rt_gifbmp.cpp); rt_image_decode_png is the PNG side: ISO/IEC 15948 with the inflate of RFC 1950 / 1951 written out here. Every colour type and bit
 // depth, Adam7 interlacing, all five row filters; CRC-32 of every chunk and the Adler-32 of the image data
 // are checked. PNG is lossless, so there is no choice of reconstruction to match: an 8-bit RGB file gives
 // exactly the bytes the reference's raster read (texture.clj:73-77, a TYPE_3BYTE_BGR raster reversed to
@@ -441,6 +441,8 @@ extern "C" int rt_image_decode(const uint8_t* bytes, uint64_t n_bytes, int32_t* 
   if (n_bytes >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) return rt_image_decode_jpeg(bytes, n_bytes, width, height, rgb8, capacity);
   if (n_bytes >= 4 && bytes[0] == 0x89 && bytes[1] == 'P' && bytes[2] == 'N' && bytes[3] == 'G')
     return rt_image_decode_png(bytes, n_bytes, width, height, rgb8, capacity);
+  if (n_bytes >= 4 && memcmp(bytes, "GIF8", 4) == 0) return rt_image_decode_gif(bytes, n_bytes, width, height, rgb8, capacity);
+  if (n_bytes >= 2 && bytes[0] == 'B' && bytes[1] == 'M') return rt_image_decode_bmp(bytes, n_bytes, width, height, rgb8, capacity);
   *width = *height = 0;
-  return rt::fail(RT_ERR_UNSUPPORTED, "rt_image_decode: neither a JPEG nor a PNG file by its first bytes (GIF, BMP and WBMP, which ImageIO also reads, are not covered)");
+  return rt::fail(RT_ERR_UNSUPPORTED, "rt_image_decode: not a JPEG, PNG, GIF or BMP file by its first bytes (WBMP and TIFF, which ImageIO also reads, are not covered)");
 }

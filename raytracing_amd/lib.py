@@ -19,7 +19,8 @@ EXPORTS = ["rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version", "rt_scen
            "rt_scene_create_with", "rt_scene_bvh_digest", "rt_scene_get_variants", "rt_hit_batch_variant", "rt_scatter_batch",
            "rt_render_device_noalloc", "rt_get_device_info", "rt_multi_init", "rt_multi_shutdown",
            "rt_multi_device_count", "rt_multi_selftest_rccl", "rt_multi_last_error", "rt_multi_scene_create", "rt_multi_scene_destroy",
-           "rt_multi_render", "rt_image_decode_jpeg", "rt_image_decode_png", "rt_image_decode"]
+           "rt_multi_render", "rt_image_decode_jpeg", "rt_image_decode_png", "rt_image_decode_gif", "rt_image_decode_bmp",
+           "rt_image_decode"]
 
 _LIB = None
 
@@ -60,7 +61,7 @@ def load():
     L.rt_hit_batch_variant.argtypes = [vp, vp, C.c_int32, C.c_int32, fp, fp, fp, C.c_float, C.c_float, fp,
                                        C.POINTER(abi.rt_hit)]
     L.rt_scatter_batch.argtypes = [vp, vp, C.c_uint64, C.c_int32, fp, fp, fp, ip, ip, ip, C.POINTER(abi.rt_scatter)]
-    for f in (L.rt_image_decode_jpeg, L.rt_image_decode_png, L.rt_image_decode):
+    for f in (L.rt_image_decode_jpeg, L.rt_image_decode_png, L.rt_image_decode_gif, L.rt_image_decode_bmp, L.rt_image_decode):
         f.argtypes = [C.c_char_p, C.c_uint64, ip, ip, vp, C.c_uint64]
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_scene_destroy.restype = None
@@ -187,8 +188,18 @@ def decode_png(data: bytes) -> np.ndarray:
     return _decode("rt_image_decode_png", data)
 
 
+def decode_gif(data: bytes) -> np.ndarray:
+    """The first image of a GIF file (rt_image_decode_gif)."""
+    return _decode("rt_image_decode_gif", data)
+
+
+def decode_bmp(data: bytes) -> np.ndarray:
+    """A BMP file (rt_image_decode_bmp)."""
+    return _decode("rt_image_decode_bmp", data)
+
+
 def decode_image(data: bytes) -> np.ndarray:
-    """ImageIO/read of texture.clj:72: JPEG or PNG, told apart by the first bytes (rt_image_decode)."""
+    """ImageIO/read of texture.clj:72: JPEG, PNG, GIF or BMP, told apart by the first bytes (rt_image_decode)."""
     return _decode("rt_image_decode", data)
 
 

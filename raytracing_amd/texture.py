@@ -86,7 +86,7 @@ ASSET_DIR = os.path.join(os.path.dirname(__file__), "assets")
 
 def load_rgb8(path: str) -> np.ndarray:
     """Decode an image file to (h, w, 3) uint8, as ImageIO/read does for the reference (texture.clj:72).
-    JPEG and PNG files (told apart by their first bytes, whatever the name: resources/map2.png is a JPEG)
+    JPEG, PNG, GIF and BMP files (told apart by their first bytes, whatever the name: resources/map2.png is a JPEG)
     are decoded by the library's own decoders, rt_image_decode; `.npz` files (key 'rgb8') hold decoded arrays."""
     if path.endswith(".npz"):
         with np.load(path) as z:

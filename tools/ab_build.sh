@@ -6,5 +6,5 @@ cd "$(dirname "$0")/../raytracing_amd/csrc"
 TAG=$1; shift
 mkdir -p ../../ab
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function -Wno-unused-value -Wno-unused-result -fno-gpu-rdc \
-  "$@" -shared -o ../../ab/librtmi_$TAG.so rt_api.hip rt_kernels.hip rt_bvh.hip rt_multi.hip rt_jpeg.cpp rt_png.cpp -ldl -lpthread
+  "$@" -shared -o ../../ab/librtmi_$TAG.so rt_api.hip rt_kernels.hip rt_bvh.hip rt_multi.hip rt_jpeg.cpp rt_png.cpp rt_gifbmp.cpp -ldl -lpthread
 echo built ab/librtmi_$TAG.so

@@ -3,10 +3,10 @@
 // library wants its runtime loaded before the interpreter. Needs a GPU.
 //   hipcc -O1 -g -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -fno-gpu-rdc -Xarch_host -fsanitize=address \
 //     -Xarch_host -fsanitize=undefined -shared -o librtmi_asan.so raytracing_amd/csrc/{rt_api,rt_kernels,rt_bvh,rt_multi}.hip \
-//     raytracing_amd/csrc/rt_jpeg.cpp raytracing_amd/csrc/rt_png.cpp -ldl -lpthread
+//     raytracing_amd/csrc/rt_jpeg.cpp raytracing_amd/csrc/rt_png.cpp raytracing_amd/csrc/rt_gifbmp.cpp -ldl -lpthread
 //   hipcc -O1 -g -std=c++17 --offload-arch=gfx950 -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined \
 //     tools/fuzz/api_walk.cpp -L. -lrtmi_asan -Wl,-rpath,'$ORIGIN' -o api_walk
-//   ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 ./api_walk <scene files written by rt_scene_write> -- <JPEG and PNG files>
+//   ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 ./api_walk <scene files written by rt_scene_write> -- <JPEG, PNG, GIF and BMP files>
 #include <hip/hip_runtime.h>
 #include <unistd.h>
 #include <cstdint>
@@ -214,14 +214,16 @@ int main(int argc, char** argv) {
   for (++a; a < argc; ++a) {
     const std::vector<uint8_t> file = slurp(argv[a]);
     int32_t w = 0, h = 0;
-    // by content (JPEG or PNG), then once more through the decoder the first bytes name
+    // by content (JPEG, PNG, GIF or BMP), then once more through the decoder the first bytes name
     OK(rt_image_decode(file.data(), file.size(), &w, &h, nullptr, 0));
     std::vector<uint8_t> rgb((size_t)w * (size_t)h * 3), again(rgb.size());
     OK(rt_image_decode(file.data(), file.size(), &w, &h, rgb.data(), rgb.size()));
-    const bool png = file.size() > 1 && file[0] == 0x89;
-    OK((png ? rt_image_decode_png : rt_image_decode_jpeg)(file.data(), file.size(), &w, &h, again.data(), again.size()));
+    const uint8_t c0 = file.empty() ? 0 : file[0];
+    const char* kind = c0 == 0x89 ? "PNG" : c0 == 'G' ? "GIF" : c0 == 'B' ? "BMP" : "JPEG";
+    OK((c0 == 0x89 ? rt_image_decode_png : c0 == 'G' ? rt_image_decode_gif : c0 == 'B' ? rt_image_decode_bmp : rt_image_decode_jpeg)(
+        file.data(), file.size(), &w, &h, again.data(), again.size()));
     if (rgb != again) { printf("%s: the two entry points disagree\n", argv[a]); return 1; }
-    printf("%s: %d x %d (%s)\n", argv[a], w, h, png ? "PNG" : "JPEG");
+    printf("%s: %d x %d (%s)\n", argv[a], w, h, kind);
   }
   // what must be refused is refused
   {

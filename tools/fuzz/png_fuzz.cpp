@@ -1,5 +1,5 @@
 // Mutation fuzz of rt_image_decode_png (and the sniffing rt_image_decode) under AddressSanitizer / UBSan (host code only, no GPU):
-//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined tools/fuzz/png_fuzz.cpp raytracing_amd/csrc/rt_png.cpp raytracing_amd/csrc/rt_jpeg.cpp -o /tmp/png_fuzz
+//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined tools/fuzz/png_fuzz.cpp raytracing_amd/csrc/rt_png.cpp raytracing_amd/csrc/rt_jpeg.cpp raytracing_amd/csrc/rt_gifbmp.cpp -o /tmp/png_fuzz
 //   ASAN_OPTIONS=detect_leaks=0:allocator_may_return_null=1 /tmp/png_fuzz <iterations> <seed> <file.png> [more files]
 // A PNG's chunks carry CRCs, so a blind byte flip stops at the first gate. Half of the mutations therefore edit the
 // BODY of a chunk (header, palette or image data: bytes overwritten, pieces cut out or doubled) and write the chunk's

@@ -2,7 +2,7 @@
 // (needs a GPU: a scene that passes validation is flattened, its trees are built and its tables uploaded).
 //   hipcc -O1 -g -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -fno-gpu-rdc -Xarch_host -fsanitize=address \
 //     -Xarch_host -fsanitize=undefined -shared -o librtmi_asan.so raytracing_amd/csrc/{rt_api,rt_kernels,rt_bvh,rt_multi}.hip \
-//     raytracing_amd/csrc/rt_jpeg.cpp raytracing_amd/csrc/rt_png.cpp -ldl -lpthread
+//     raytracing_amd/csrc/rt_jpeg.cpp raytracing_amd/csrc/rt_png.cpp raytracing_amd/csrc/rt_gifbmp.cpp -ldl -lpthread
 //   /opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -fsanitize=address,undefined tools/fuzz/scene_fuzz.cpp -L. -lrtmi_asan \
 //     -Wl,-rpath,'$ORIGIN' -o scene_fuzz
 //   ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 ./scene_fuzz <mutations per file> <seed> <scene files written by rt_scene_write>
