@@ -1,7 +1,8 @@
 """rt_render_device_noalloc (scratch in a fixed device array inside the library, no allocation)
 against rt_render_device, through the C ABI: bit-identical sums and pixels on two calls in a row,
 the second with a smaller input (the array keeps the first call's contents), then a third on
-another world, a request beyond the array's size, and a run on a side stream."""
+another world, a request beyond the array's size, and a run on a side stream; then the call captured into a HIP
+graph (one of the callers it exists for) and replayed."""
 import numpy as np
 import pytest
 
@@ -71,4 +72,32 @@ def test_noalloc_matches_render_device(gpu_ctx):
     p = abi.make_params(96, 64, 6, 50, cfg["background"], seed=43)
     (a_rgb, a_argb), (b_rgb, b_argb) = _both(sc, cam, p, stream=torch.cuda.Stream())
     assert np.array_equal(a_rgb.view(np.uint32), b_rgb.view(np.uint32)) and np.array_equal(a_argb, b_argb)
+    sc.close()
+
+
+def test_noalloc_call_is_capturable(gpu_ctx):
+    """Stream capture forbids allocation and synchronisation: the call goes into a graph as it is (two memsets, the
+    path kernel, resolve and tonemap) and every replay gives the frame of rt_render_device bit for bit."""
+    import torch
+    cfg, flat, cam = scene_bundle("cornell-box")
+    sc = gpu_ctx.scene(flat)
+    p = abi.make_params(64, 48, 12, 50, cfg["background"], seed=77)
+    H, W = p.height, p.width
+    want_rgb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    want_argb = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+    sc.render_device(cam, p, want_rgb.data_ptr(), want_argb.data_ptr())
+    torch.cuda.synchronize()
+    rgb = torch.full((H, W, 3), -7.0, dtype=torch.float32, device="cuda:0")
+    argb = torch.full((H, W), 0x55, dtype=torch.int32, device="cuda:0")
+    sc.render_device_noalloc(cam, p, rgb.data_ptr(), argb.data_ptr())      # first call on the device: the library's set-up is done
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sc.render_device_noalloc(cam, p, rgb.data_ptr(), argb.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        rgb.fill_(-7.0)
+        argb.fill_(0x55)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(rgb.view(torch.int32), want_rgb.view(torch.int32)) and torch.equal(argb, want_argb)
     sc.close()
